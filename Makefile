@@ -1,0 +1,45 @@
+# Builds the three native pieces in-tree (the .so files travel to the GPU box, they are not in git):
+#   raytracer_amd/lib/librtcore.so   HIP render core for gfx950 (the product)
+#   raytracer_amd/lib/librthost.so   host-side mirror of the reference's scene set-up (the product's host)
+#   raytracer_amd/bin/rtcli          C++ mirror of `cabal run raytracer <config.json>` (app/Main.hs)
+#   oracle/_build/liboracle.so       CPU FP64 restatement of the reference (TEST INFRASTRUCTURE ONLY)
+HIPCC   ?= hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+RT_MIN_WAVES ?= 2
+
+CORE_SRC := raytracer_amd/csrc/rtcore.hip
+CORE_HDR := raytracer_amd/csrc/rt_kernels.h raytracer_amd/csrc/rt_device.h include/rtcore.h
+HOST_SRC := $(wildcard raytracer_amd/csrc/host/*.cpp)
+HOST_HDR := include/rthost.h include/rtcore.h
+
+all: core host cli oracle
+
+core: raytracer_amd/lib/librtcore.so
+host: raytracer_amd/lib/librthost.so
+cli: raytracer_amd/bin/rtcli
+oracle: oracle/_build/liboracle.so
+
+raytracer_amd/lib/librtcore.so: $(CORE_SRC) $(CORE_HDR)
+	@mkdir -p raytracer_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(CORE_SRC) -o $@
+
+# -ffp-contract=off: the BVH builder's sort keys must round exactly like the reference's doubles
+raytracer_amd/lib/librthost.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p raytracer_amd/lib
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -pthread $(HOST_SRC) -o $@
+
+raytracer_amd/bin/rtcli: raytracer_amd/csrc/rtcli.cpp raytracer_amd/lib/librtcore.so raytracer_amd/lib/librthost.so
+	@mkdir -p raytracer_amd/bin
+	$(CXX) -O2 -std=c++17 raytracer_amd/csrc/rtcli.cpp -Iinclude -Lraytracer_amd/lib -lrtcore -lrthost \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib -o $@
+
+# -ffp-contract=off: GHC forms no FMAs; neither may the restatement
+oracle/_build/liboracle.so: oracle/oracle.cpp include/rtcore.h
+	@mkdir -p oracle/_build
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -pthread oracle/oracle.cpp -o $@
+
+clean:
+	rm -rf raytracer_amd/lib raytracer_amd/bin oracle/_build
+
+.PHONY: all core host cli oracle clean

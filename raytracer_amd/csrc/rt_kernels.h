@@ -1,0 +1,496 @@
+// rt_kernels.h — the wave64 persistent-thread render kernel of the MI355X render core.
+//
+// One wave = one 8x8-pixel tile (lane <-> pixel).  Waves pull tile indices from an atomic
+// counter until the frame (or this rank's tile subset) is exhausted.  Inside a tile every lane
+// runs its own path state machine: it walks its pixel's samples 0..spp-1 in order (so the sum
+// order equals the reference's foldl', RenderWorker.hs:111-114) and never waits for another
+// lane between rays; each trip of the outer loop does exactly ONE BVH query per active lane
+// (closest-hit for camera/bounce rays, any-hit for shadow rays), followed by a short
+// divergent state transition.
+//
+// Reference semantics restated here (paths relative to /root/reference/app):
+//   camera_ray            Rendering/Camera.hs:47-60, Rendering/RenderWorker.hs:95-106
+//   traversal             Hittable/BVH.hs:120-143, Hittable/BoundingBox.hs:18-37
+//   primitive tests       Hittable/Objects/{Triangle.hs:30-64, Sphere.hs:24-40, Plane.hs:21-32}
+//   shadow rays           Rendering/Light.hs:16-49
+//   material bounce       Rendering/Trace.hs:22-76
+//   background / sky      Rendering/ImageGenerator.hs:130-135, Rendering/SkySphere.hs:32-47
+//   tone map, gamma       Rendering/Trace.hs:96-105
+#pragma once
+#include "rt_device.h"
+#include "../../include/rtcore.h"
+
+struct KScene {
+  const void *nodes;           // DNode<BT>[]
+  const DPrim *prims;
+  const int32_t *prim_ids;
+  const DMaterial *mats;
+  const DLight *lights;
+  const double *plane_boxes;   // 6 doubles per plane: the FP64 box of the leaf holding it
+  const void *sky;
+  int32_t root_ref;
+  int32_t n_lights;
+  int32_t bg_kind, sky_format, sky_w, sky_h;
+  double bg1[3], bg2[3];
+  float rscene;                // max |coordinate| of the root box
+};
+
+struct KFrame {
+  rt_camera cam;
+  int32_t W, H, spp, aa, maxb;
+  double exposure, gamma;
+  uint32_t key0, key1;
+  const int32_t *tiles;        // this rank's tile ids, or NULL = all tiles in order
+  int32_t n_tiles, tiles_x;
+  int32_t packed;              // 1: outputs indexed by local_tile*64+lane ; 0: row-major full frame
+  double *out_color, *out_radiance;
+  int32_t *out_primid;
+  uint32_t *tile_counter;
+  unsigned long long *stats;   // 8 counters, see STAT_*
+  int32_t stack_depth;
+};
+
+enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_COUNT };
+
+#define RT_TMIN 0.001
+#define RT_TMAX 10000.0
+
+// ---------------------------------------------------------------- camera (Camera.hs:47-60)
+RT_DEV void camera_ray(const KFrame &fr, int px, int py, uint32_t pixel, uint32_t sample, d3 &o, d3 &d) {
+  double uo = 0.5, vo = 0.5, lx = 0.0, ly = 0.0;                  // RenderWorker.hs:98-99
+  const double ap = fr.cam.aperture;
+  if (fr.aa || ap != 0.0) {
+    u4 w = philox4x32_10(pixel, sample, 0u, 0u, fr.key0, fr.key1);
+    if (fr.aa) { uo = u01(w.x); vo = u01(w.y); }
+    if (ap != 0.0) {                                              // randomInUnitDisk, Vec3.hs:126-133
+      lx = um11(w.z); ly = um11(w.w);
+      uint32_t sub = 1;
+      while (!(lx * lx + ly * ly < 1.0) && sub < 64u) {
+        w = philox4x32_10(pixel, sample, 0u, sub, fr.key0, fr.key1);
+        lx = um11(w.x); ly = um11(w.y);
+        if (!(lx * lx + ly * ly < 1.0)) { lx = um11(w.z); ly = um11(w.w); }
+        ++sub;
+      }
+      if (!(lx * lx + ly * ly < 1.0)) { lx = 0.0; ly = 0.0; }
+    }
+  }
+  d3 lens = (ap / 2) * (lx * ld3(fr.cam.u) + ly * ld3(fr.cam.v));   // :50
+  o = ld3(fr.cam.origin) + lens;                                    // :51
+  double rayu = ((double)px + uo) / (double)fr.W;                   // :54
+  double rayv = ((double)(fr.H - 1 - py) + vo) / (double)fr.H;      // :55 with j = rowIdx (RenderWorker.hs:66)
+  d3 dir = ((ld3(fr.cam.lower_left) + rayu * ld3(fr.cam.horizontal)) + rayv * ld3(fr.cam.vertical)) - o;   // :56-59
+  d = normalize3(dir);                                              // :60
+}
+
+// ---------------------------------------------------------------- background (Trace.hs:78-83)
+RT_DEV d3 background(const KScene &sc, d3 dir) {
+  if (sc.sky_format != RT_SKY_NONE) {                               // SkySphere.hs:32-47
+    d3 n = normalize3(dir);
+    double dy = fmax(-1.0, fmin(1.0, n.y));
+    double u = 0.5 + atan2(n.z, n.x) / (2 * 3.14159265358979323846);
+    double v = 0.5 - asin(dy) / 3.14159265358979323846;
+    long long i = (long long)floor(u * (double)sc.sky_w), j = (long long)floor(v * (double)sc.sky_h);
+    i = i < 0 ? 0 : (i > sc.sky_w - 1 ? sc.sky_w - 1 : i);
+    j = j < 0 ? 0 : (j > sc.sky_h - 1 ? sc.sky_h - 1 : j);
+    size_t k = ((size_t)j * sc.sky_w + (size_t)i) * 3;
+    if (sc.sky_format == RT_SKY_RGB8) {
+      const uint8_t *p = (const uint8_t *)sc.sky;
+      return mk3(p[k] / 255.0, p[k + 1] / 255.0, p[k + 2] / 255.0);
+    }
+    const float *p = (const float *)sc.sky;
+    return mk3((double)p[k], (double)p[k + 1], (double)p[k + 2]);
+  }
+  if (sc.bg_kind == RT_BG_SOLID) return ld3(sc.bg1);                // ImageGenerator.hs:131
+  d3 unit = normalize3(dir);                                        // :133
+  double t = 0.5 * (unit.y + 1.0);                                  // :134
+  return (1.0 - t) * ld3(sc.bg2) + t * ld3(sc.bg1);                 // :135, Color.hs:16-17
+}
+
+// ---------------------------------------------------------------- ray/box set-up
+// BoxRay<double>: the reference's slab test verbatim (BoundingBox.hs:18-37).
+// BoxRay<float> : a conservative FP32 superset of it (DESIGN.md §Conservative FP32 boxes): boxes are
+//   rounded outward at upload, the ray origin is widened by a margin m that covers the FP32 rounding of
+//   origin and direction, and the enter/exit comparison carries a relative slack, so a box the FP64
+//   test accepts is never rejected here.  Primitive tests stay FP64 either way.
+template <typename BT> struct BoxRay;
+template <> struct BoxRay<double> {
+  double ox, oy, oz, ix, iy, iz;
+  bool px, py, pz;
+};
+template <> struct BoxRay<float> {
+  float ix, iy, iz, ax, ay, az, bx, by, bz;
+};
+
+RT_DEV void make_boxray(BoxRay<double> &b, d3 o, d3 d, float) {
+  b.ox = o.x; b.oy = o.y; b.oz = o.z;
+  b.px = fabs(d.x) < 1e-8; b.py = fabs(d.y) < 1e-8; b.pz = fabs(d.z) < 1e-8;      // :21
+  b.ix = 1.0 / d.x; b.iy = 1.0 / d.y; b.iz = 1.0 / d.z;                           // :24
+}
+RT_DEV float safe_dir(float v) { return fabsf(v) < 1e-30f ? (v < 0.0f ? -1e-30f : 1e-30f) : v; }
+RT_DEV void make_boxray(BoxRay<float> &b, d3 o, d3 d, float rscene) {
+  float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  float omax = fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz)));
+  // reachable region: |coord| <= omax + 1e4 (t <= 10000, |d| ~ 1), clipped to the scene
+  float m = 9.5367431640625e-7f * (fminf(rscene, omax + 1.0e4f) + omax) + 1e-30f;   // 2^-20 * extent
+  b.ix = 1.0f / safe_dir((float)d.x); b.iy = 1.0f / safe_dir((float)d.y); b.iz = 1.0f / safe_dir((float)d.z);
+  b.ax = (ox + m) * b.ix; b.ay = (oy + m) * b.iy; b.az = (oz + m) * b.iz;
+  b.bx = (ox - m) * b.ix; b.by = (oy - m) * b.iy; b.bz = (oz - m) * b.iz;
+}
+
+// Slab test of one child box against [tmin, tmax]; returns hit and the entry distance.
+RT_DEV bool box_test(const BoxRay<double> &r, const double *bx, double tmin, double tmax, double &tenter) {
+  double a0, a1, b0, b1, c0, c1;
+  const double inf = __builtin_huge_val();
+  bool ok = true;
+  if (r.px) { ok = ok && !(r.ox < bx[0] || r.ox > bx[3]); a0 = -inf; a1 = inf; }
+  else { double t0 = (bx[0] - r.ox) * r.ix, t1 = (bx[3] - r.ox) * r.ix; a0 = fmin(t0, t1); a1 = fmax(t0, t1); }
+  if (r.py) { ok = ok && !(r.oy < bx[1] || r.oy > bx[4]); b0 = -inf; b1 = inf; }
+  else { double t0 = (bx[1] - r.oy) * r.iy, t1 = (bx[4] - r.oy) * r.iy; b0 = fmin(t0, t1); b1 = fmax(t0, t1); }
+  if (r.pz) { ok = ok && !(r.oz < bx[2] || r.oz > bx[5]); c0 = -inf; c1 = inf; }
+  else { double t0 = (bx[2] - r.oz) * r.iz, t1 = (bx[5] - r.oz) * r.iz; c0 = fmin(t0, t1); c1 = fmax(t0, t1); }
+  tenter = fmax(fmax(a0, b0), fmax(c0, tmin));                     // :30
+  double texit = fmin(fmin(a1, b1), fmin(c1, tmax));               // :31
+  return ok && tenter <= texit;                                    // :32
+}
+#define RT_SLACK 1.000001f
+RT_DEV bool box_test(const BoxRay<float> &r, const float *bx, float tmin, float tmax, float &tenter) {
+  float tlx = fmaf(bx[0], r.ix, -r.ax), thx = fmaf(bx[3], r.ix, -r.bx);
+  float tly = fmaf(bx[1], r.iy, -r.ay), thy = fmaf(bx[4], r.iy, -r.by);
+  float tlz = fmaf(bx[2], r.iz, -r.az), thz = fmaf(bx[5], r.iz, -r.bz);
+  tenter = fmaxf(fmaxf(fminf(tlx, thx), fminf(tly, thy)), fmaxf(fminf(tlz, thz), tmin));
+  float texit = fminf(fminf(fmaxf(tlx, thx), fmaxf(tly, thy)), fminf(fmaxf(tlz, thz), tmax));
+  return tenter <= texit * RT_SLACK;
+}
+
+template <typename BT> RT_DEV BT tmax_for_boxes(double best_t);
+template <> RT_DEV double tmax_for_boxes<double>(double best_t) { return best_t; }
+template <> RT_DEV float tmax_for_boxes<float>(double best_t) { return __double2float_ru(best_t); }
+template <typename BT> RT_DEV BT tmin_for_boxes();
+template <> RT_DEV double tmin_for_boxes<double>() { return RT_TMIN; }
+template <> RT_DEV float tmin_for_boxes<float>() { return 0.00099999f; }
+// pop-time cull: true when a stacked entry distance is provably beyond the closest hit so far
+RT_DEV bool cull_entry(float tenter, double tmaxb) { return (double)tenter > tmaxb; }
+RT_DEV bool cull_entry(float tenter, float tmaxb) { return tenter > tmaxb * RT_SLACK; }
+
+// ---------------------------------------------------------------- primitive tests (FP64, reference order of operations)
+RT_DEV bool hit_triangle(const DPrim &P, d3 ro, d3 rd, double tmin, double tmax, double &tout) {
+  d3 p0 = mk3(P.d[0], P.d[1], P.d[2]), e1 = mk3(P.d[3], P.d[4], P.d[5]), e2 = mk3(P.d[6], P.d[7], P.d[8]);
+  d3 h = cross3(rd, e2);                       // Triangle.hs:34
+  double a = dot3(e1, h);                      // :35
+  if (fabs(a) < 1e-8) return false;            // :36
+  double f = 1.0 / a;                          // :39
+  d3 s = ro - p0;                              // :40
+  double u = f * dot3(s, h);                   // :41
+  if (u < 0.0 || u > 1.0) return false;        // :42
+  d3 q = cross3(s, e1);                        // :45
+  double v = f * dot3(rd, q);                  // :46
+  if (v < 0.0 || u + v > 1.0) return false;    // :47
+  double t = f * dot3(e2, q);                  // :50
+  if (!(t >= tmin && t <= tmax)) return false; // :53 contains
+  tout = t;
+  return true;
+}
+RT_DEV bool hit_sphere(const DPrim &P, d3 ro, d3 rd, double tmin, double tmax, double &tout) {
+  d3 c = mk3(P.d[0], P.d[1], P.d[2]);
+  double r = P.d[3];
+  d3 oc = ro - c;                                              // Sphere.hs:29
+  double a = dot3(rd, rd);                                     // :30
+  double h = dot3(oc, rd);                                     // :31
+  double disc = h * h - a * (dot3(oc, oc) - r * r);            // :32
+  if (disc < 0) return false;                                  // :25
+  double t1 = (-h - sqrt(disc)) / a;                           // :33-34 (near root only)
+  if (!(t1 >= tmin && t1 <= tmax)) return false;               // :26
+  tout = t1;
+  return true;
+}
+// Planes are bounded only by the clipped interval of the leaf that holds them (Plane.hs:20 gives every
+// plane the same slab box), so the leaf's FP64 box is re-tested exactly here.
+RT_DEV bool hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double &tout) {
+  d3 pp = mk3(P.d[0], P.d[1], P.d[2]), n = mk3(P.d[3], P.d[4], P.d[5]);
+  double denom = dot3(rd, n);                                  // Plane.hs:22
+  if (!(fabs(denom) > 1e-6)) return false;                     // :23
+  double t = dot3(pp - ro, n) / denom;                         // :25
+  double lo = tmin, hi = tmax;
+  long long bi = (long long)P.d[6];
+  if (bi >= 0) {
+    BoxRay<double> br;
+    make_boxray(br, ro, rd, 0.0f);
+    double te;
+    const double *bx = plane_boxes + 6 * bi;
+    if (!box_test(br, bx, tmin, tmax, te)) return false;
+    lo = te;
+    // exit distance of the same box (recomputed; box_test only returns the entry)
+    const double inf = __builtin_huge_val();
+    double a1 = br.px ? inf : fmax((bx[0] - br.ox) * br.ix, (bx[3] - br.ox) * br.ix);
+    double b1 = br.py ? inf : fmax((bx[1] - br.oy) * br.iy, (bx[4] - br.oy) * br.iy);
+    double c1 = br.pz ? inf : fmax((bx[2] - br.oz) * br.iz, (bx[5] - br.oz) * br.iz);
+    hi = fmin(fmin(a1, b1), fmin(c1, tmax));
+  }
+  if (!(t >= lo && t <= hi)) return false;                     // :26
+  tout = t;
+  return true;
+}
+
+RT_DEV unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- the render kernel
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 2
+#endif
+template <typename BT, bool STATS>
+__global__ __launch_bounds__(256, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
+  extern __shared__ uint2 lds_stack[];                     // [wave][entry][lane]
+  const int lane = threadIdx.x & 63;
+  uint2 *stack = lds_stack + (size_t)(threadIdx.x >> 6) * fr.stack_depth * 64 + lane;
+  const DNode<BT> *nodes = (const DNode<BT> *)sc.nodes;
+  const double inf = __builtin_huge_val();
+
+  uint32_t st[STAT_COUNT];
+#pragma unroll
+  for (int i = 0; i < STAT_COUNT; ++i) st[i] = 0;
+
+  for (;;) {
+    uint32_t ti = 0;
+    if (lane == 0) ti = atomicAdd(fr.tile_counter, 1u);
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    if (ti >= (uint32_t)fr.n_tiles) break;
+    const int tile = fr.tiles ? fr.tiles[ti] : (int)ti;
+    const int px = (tile % fr.tiles_x) * 8 + (lane & 7);
+    const int py = (tile / fr.tiles_x) * 8 + (lane >> 3);
+    const bool inimg = px < fr.W && py < fr.H;
+    const uint32_t pixel = (uint32_t)(py * fr.W + px);
+
+    d3 sum = mk3(0, 0, 0);
+    int pid0 = -1;
+
+    if (inimg && fr.maxb <= 0) {
+      // traceLoop _ 0: every sample is the background along its camera ray (Trace.hs:22)
+      for (int s = 0; s < fr.spp; ++s) {
+        d3 o, d;
+        camera_ray(fr, px, py, pixel, (uint32_t)s, o, d);
+        sum = sum + background(sc, d);
+      }
+    } else if (inimg) {
+      d3 ro, rd, udir = mk3(0, 0, 0), nrm = mk3(0, 0, 0), direct = mk3(0, 0, 0);
+      d3 atten, Fa, FL, FH;
+      int s = 0, bounce = 0, li = -1, hit_mat = 0;
+      bool front = false;
+      double q_tmax = RT_TMAX;
+      camera_ray(fr, px, py, pixel, 0u, ro, rd);
+      atten = mk3(1, 1, 1); Fa = mk3(0, 0, 0); FL = mk3(-inf, -inf, -inf); FH = mk3(inf, inf, inf);
+
+      bool active = true;
+      while (active) {
+        // ------------------------------------------------ one BVH query (BVH.hs:120-143)
+        const bool anyhit = li >= 0;
+        double best_t = q_tmax;
+        int best = -1;
+        if (STATS) st[anyhit ? STAT_SHADOW : STAT_CLOSEST]++;
+        {
+          BoxRay<BT> br;
+          make_boxray(br, ro, rd, sc.rscene);
+          const BT tminb = tmin_for_boxes<BT>();
+          BT tmaxb = tmax_for_boxes<BT>(best_t);
+          int sp = 0;
+          int cur = sc.root_ref;
+          bool tdone = false;
+          while (!tdone) {
+            if (cur >= 0) {
+              const DNode<BT> nd = nodes[cur];
+              if (STATS) st[STAT_NODES]++;
+              BT tL, tR;
+              const bool hL = box_test(br, nd.box, tminb, tmaxb, tL);
+              const bool hR = box_test(br, nd.box + 6, tminb, tmaxb, tR);
+              if (hL && hR) {
+                const bool lf = tL < tR;                     // :132 (tie => right first)
+                const BT ts = lf ? tR : tL;
+                float tsf;
+                if constexpr (sizeof(BT) == 8) tsf = __double2float_rd((double)ts); else tsf = (float)ts;
+                stack[sp * 64] = make_uint2((uint32_t)(lf ? nd.ref[1] : nd.ref[0]), __float_as_uint(tsf));
+                ++sp;
+                cur = lf ? nd.ref[0] : nd.ref[1];
+                continue;
+              }
+              if (hL) { cur = nd.ref[0]; continue; }
+              if (hR) { cur = nd.ref[1]; continue; }
+            } else {
+              int pi = ~cur;
+              for (;;) {                                     // closestHitList over the leaf, HitHelpers.hs:11-16
+                const DPrim P = sc.prims[pi];
+                const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+                double t;
+                bool h;
+                if (kind == RT_PRIM_TRIANGLE) { if (STATS) st[STAT_TRI]++; h = hit_triangle(P, ro, rd, RT_TMIN, best_t, t); }
+                else if (kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro, rd, RT_TMIN, best_t, t); }
+                else { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro, rd, RT_TMIN, best_t, t); }
+                if (h) {                                     // t <= best_t: a later element wins ties
+                  best_t = t; best = pi;
+                  tmaxb = tmax_for_boxes<BT>(best_t);
+                  if (anyhit) { tdone = true; break; }
+                }
+                if (P.kind & DPRIM_LAST) break;
+                ++pi;
+              }
+              if (tdone) break;
+            }
+            for (;;) {                                       // pop, skipping entries beyond the closest hit
+              if (sp == 0) { tdone = true; break; }
+              --sp;
+              const uint2 e = stack[sp * 64];
+              cur = (int)e.x;
+              if (!cull_entry(__uint_as_float(e.y), tmaxb)) break;
+            }
+          }
+        }
+
+        // ------------------------------------------------ state transition
+        bool need_scatter = false, need_finish = false;
+        d3 T = mk3(0, 0, 0);
+        if (!anyhit) {
+          if (best < 0) {                                    // Trace.hs:25
+            T = atten * background(sc, rd);
+            need_finish = true;
+          } else {
+            if (s == 0 && bounce == 0) pid0 = sc.prim_ids[best];
+            const DPrim P = sc.prims[best];
+            const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+            hit_mat = P.mat;
+            const d3 hp = ro + best_t * rd;                  // R.at ray t
+            d3 outward;
+            if (kind == RT_PRIM_TRIANGLE) outward = normalize3(cross3(mk3(P.d[3], P.d[4], P.d[5]), mk3(P.d[6], P.d[7], P.d[8])));   // Triangle.hs:51
+            else if (kind == RT_PRIM_SPHERE) outward = (1.0 / P.d[3]) * (hp - mk3(P.d[0], P.d[1], P.d[2]));                        // Sphere.hs:38
+            else outward = mk3(P.d[3], P.d[4], P.d[5]);                                                                            // Plane.hs:29
+            front = dot3(rd, outward) < 0;                   // Class.hs:24
+            nrm = front ? outward : neg3(outward);           // :25
+            udir = normalize3(rd);                           // Trace.hs:32
+            ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
+            direct = mk3(0, 0, 0);
+            if (STATS) st[STAT_SHADED]++;
+            if (sc.n_lights > 0) li = sc.n_lights - 1; else need_scatter = true;
+          }
+        } else {
+          if (best < 0) {                                    // unblocked: Light.hs:36-38 / :48-49
+            const DLight L = sc.lights[li];
+            const d3 lnormal = normalize3(nrm);              // Light.hs:19
+            const double lightPower = fmax(0.0, dot3(lnormal, rd));
+            d3 contrib;
+            if (L.kind == RT_LIGHT_POINT) {
+              const d3 tl = ld3(L.vec) - ro;
+              const double dist = sqrt(dot3(tl, tl));
+              const double attenuation = 1 / (dist * dist);
+              contrib = (lightPower * attenuation) * ld3(L.intensity);
+            } else {
+              contrib = lightPower * ld3(L.intensity);
+            }
+            direct = contrib + direct;                       // foldr V.add, Light.hs:21
+          }
+          --li;
+          if (li < 0) need_scatter = true;
+        }
+        if (!need_scatter && !need_finish) {                 // set up the shadow ray towards light li (Light.hs:26-30, 39-42)
+          const DLight L = sc.lights[li];
+          if (L.kind == RT_LIGHT_POINT) {
+            const d3 tl = ld3(L.vec) - ro;
+            rd = normalize3(tl);
+            q_tmax = sqrt(dot3(tl, tl)) - 0.01;
+          } else {
+            rd = normalize3(-1.0 * ld3(L.vec));
+            q_tmax = RT_TMAX;
+          }
+        }
+        if (need_scatter) {                                  // Trace.hs:27-76
+          const DMaterial M = sc.mats[hit_mat];
+          const d3 surf = ld3(M.diffuse);
+          const d3 c = (ld3(M.emission) + surf * direct);    // emitted + litColor
+          // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + Fa, FL, FH)
+          // (DESIGN.md §Iterative form of the nested clamp): a' = a + c, L' = clamp(a', L, H), H' = clamp(a' + 10, L, H)
+          const d3 ca = c + Fa;
+          const d3 nL = clamp3(ca, FL, FH);
+          const d3 nH = clamp3(mk3(ca.x + 10.0, ca.y + 10.0, ca.z + 10.0), FL, FH);
+          FL = nL; FH = nH; Fa = ca;
+          const u4 w = philox4x32_10(pixel, (uint32_t)s, 1u + (uint32_t)bounce, 0u, fr.key0, fr.key1);
+          const d3 randVec = normalize3(mk3(um11(w.x), um11(w.y), um11(w.z)));   // :38-42
+          const double randD = u01(w.w);                                         // :41
+          if (M.flags & DMAT_GLASS_DIR) {                                        // :48-59
+            const double eta = front ? 1.0 / M.ior : M.ior;
+            const double cosTheta = fmin(-dot3(udir, nrm), 1.0);
+            const double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
+            const double r0 = (1 - eta) / (1 + eta);                             // schlick, :85-89
+            const double r0sq = r0 * r0;
+            const double reflectProb = r0sq + (1 - r0sq) * pow(1 - cosTheta, 5.0);
+            if (eta * sinTheta > 1.0 || randD < reflectProb) rd = reflect3(udir, nrm);
+            else rd = refract3(udir, nrm, eta);
+          } else if (M.flags & DMAT_METAL) {                                     // :60-64
+            rd = normalize3(reflect3(udir, nrm) + 0.05 * randVec);
+          } else {                                                               // :65-67
+            rd = normalize3(nrm + randVec);
+          }
+          if (!(M.flags & DMAT_NO_ATTEN)) atten = atten * surf;                  // :69-72
+          ++bounce;
+          li = -1;
+          q_tmax = RT_TMAX;
+          if (bounce >= fr.maxb) {                                               // depth 0: background along ray0, :22
+            d3 o0, d0;
+            camera_ray(fr, px, py, pixel, (uint32_t)s, o0, d0);
+            T = atten * background(sc, d0);
+            need_finish = true;
+          }
+        }
+        if (need_finish) {
+          sum = sum + clamp3(T + Fa, FL, FH);
+          ++s;
+          if (s < fr.spp) {
+            camera_ray(fr, px, py, pixel, (uint32_t)s, ro, rd);
+            atten = mk3(1, 1, 1); Fa = mk3(0, 0, 0); FL = mk3(-inf, -inf, -inf); FH = mk3(inf, inf, inf);
+            bounce = 0; li = -1; q_tmax = RT_TMAX;
+          } else {
+            active = false;
+          }
+        }
+      }
+    }
+
+    if (inimg) {
+      const d3 avg = (1.0 / (double)fr.spp) * sum;                               // RenderWorker.hs:114
+      const double e = fr.exposure;
+      const d3 toned = mk3(avg.x * e / (avg.x * e + 1), avg.y * e / (avg.y * e + 1), avg.z * e / (avg.z * e + 1));   // Trace.hs:96-101
+      const d3 col = mk3(pow(toned.x, fr.gamma), pow(toned.y, fr.gamma), pow(toned.z, fr.gamma));                    // :103-105
+      const size_t slot = fr.packed ? (size_t)ti * 64 + lane : (size_t)py * fr.W + px;
+      if (fr.out_color) { fr.out_color[3 * slot] = col.x; fr.out_color[3 * slot + 1] = col.y; fr.out_color[3 * slot + 2] = col.z; }
+      if (fr.out_radiance) { fr.out_radiance[3 * slot] = avg.x; fr.out_radiance[3 * slot + 1] = avg.y; fr.out_radiance[3 * slot + 2] = avg.z; }
+      if (fr.out_primid) fr.out_primid[slot] = pid0;
+    }
+  }
+
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < STAT_COUNT; ++i) {
+      unsigned long long v = wave_sum((unsigned long long)st[i]);
+      if (lane == 0 && v) atomicAdd(fr.stats + i, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- small helper kernels
+__global__ void k_untile(const int32_t *tiles, int n_tiles, int tiles_x, int W, int H, int n_comp,
+                         const double *packed, double *image) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (size_t)n_tiles * 64) return;
+  const int tile = tiles[slot >> 6], lane = (int)(slot & 63);
+  const int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
+  if (px >= W || py >= H) return;
+  const size_t dst = ((size_t)py * W + px) * n_comp;
+  for (int c = 0; c < n_comp; ++c) image[dst + c] = packed[slot * n_comp + c];
+}
+
+__global__ void k_quantize(const double *color, uint8_t *rgb8, long long n) {       // showPixel, RenderWorker.hs:108-109
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = trunc(color[i] * 255.999);
+  v = v != v ? 0.0 : (v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v));
+  rgb8[i] = (uint8_t)v;
+}

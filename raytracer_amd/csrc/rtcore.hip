@@ -1,0 +1,524 @@
+// rtcore.hip — C ABI (include/rtcore.h) of the MI355X render core: scene re-layout into HBM,
+// kernel launches, tile sharding helpers.  gfx950 only; there is NO CPU fallback: without a HIP
+// device every entry point returns RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+  } while (0)
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  int n_cu = 0;
+  size_t lds_per_block = 0;
+} g_ctx;
+
+int ensure_init() {
+  if (g_ctx.ready) return RT_OK;
+  return rt_init(-1);
+}
+
+float f32_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
+float f32_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
+
+template <typename T> int dev_upload(T **dst, const T *src, size_t n) {
+  *dst = nullptr;
+  size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  if (hipMalloc((void **)dst, bytes) != hipSuccess) return fail(RT_ERR_OOM, "hipMalloc of %zu bytes failed", bytes);
+  if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+}  // namespace
+
+static inline int tiles_x_of(int W) { return (W + 7) / 8; }
+static inline int tiles_y_of(int H) { return (H + 7) / 8; }
+
+struct rt_scene {
+  int device = 0;
+  // HBM-resident scene
+  DNode<float> *d_nodes32 = nullptr;
+  DNode<double> *d_nodes64 = nullptr;   // uploaded on first use of box_precision = 1
+  DPrim *d_prims = nullptr;
+  int32_t *d_prim_ids = nullptr;
+  DMaterial *d_mats = nullptr;
+  DLight *d_lights = nullptr;
+  double *d_plane_boxes = nullptr;
+  void *d_sky = nullptr;
+  std::vector<DNode<double>> h_nodes64;
+  KScene ks{};
+  int n_internal = 0, depth = 0;
+  // per-launch scratch
+  uint32_t *d_counter = nullptr;
+  unsigned long long *d_stats = nullptr;
+  // cached outputs of rt_render
+  size_t cap_px = 0;
+  double *d_color = nullptr, *d_radiance = nullptr;
+  int32_t *d_primid = nullptr;
+  uint8_t *d_rgb8 = nullptr;
+  // cached tile list
+  int tl_w = -1, tl_h = -1, tl_rank = -1, tl_world = -1, tl_n = 0;
+  int32_t *d_tiles = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int rt_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render core has no CPU fallback");
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= n) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  g_ctx.device = device;
+  g_ctx.n_cu = prop.multiProcessorCount;
+  g_ctx.lds_per_block = prop.sharedMemPerBlock;
+  g_ctx.ready = true;
+  return RT_OK;
+}
+
+void rt_shutdown(void) { g_ctx.ready = false; }
+
+void rt_scene_destroy(rt_scene *s) {
+  if (!s) return;
+  (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
+  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_sky);
+  (void)hipFree(s->d_counter); (void)hipFree(s->d_stats);
+  (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_tiles);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
+  if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (d->n_nodes <= 0 || d->n_prims <= 0) return fail(RT_ERR_EMPTY_SCENE, "empty scene: Cannot compute bounding box of empty list");
+  if (!d->node_bounds || !d->node_child || !d->prim_kind || !d->prim_data || !d->prim_material)
+    return fail(RT_ERR_INVALID, "scene descriptor has null arrays");
+  if (d->n_materials < 0 || d->n_lights < 0 || (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
+    return fail(RT_ERR_INVALID, "bad material/light table");
+  if (d->sky_format != RT_SKY_NONE && (d->sky_width <= 0 || d->sky_height <= 0 || !d->sky_pixels))
+    return fail(RT_ERR_INVALID, "bad sky texture");
+  if (d->sky_format < RT_SKY_NONE || d->sky_format > RT_SKY_RGBF) return fail(RT_ERR_INVALID, "bad sky format");
+
+  const int nn = d->n_nodes, np = d->n_prims;
+  // ---- validate the tree (every kernel index is checked here, on the host) and order the internal nodes:
+  //      the top levels breadth-first (they are the ones every ray touches), the subtrees below depth-first.
+  std::vector<int> level(nn, -1), dev_index(nn, -1), order;
+  std::vector<char> seen(nn, 0);
+  auto is_leaf = [&](int i) { return d->node_child[2 * i] < 0; };
+  auto check_node = [&](int i) -> int {
+    if (i < 0 || i >= nn) return fail(RT_ERR_INVALID, "node index %d out of range", i);
+    if (seen[i]) return fail(RT_ERR_INVALID, "node %d reachable twice: not a tree", i);
+    seen[i] = 1;
+    if (is_leaf(i)) {
+      long first = -1L - d->node_child[2 * i], cnt = d->node_child[2 * i + 1];
+      if (first < 0 || cnt < 1 || first + cnt > np) return fail(RT_ERR_INVALID, "leaf %d has bad primitive range", i);
+    } else if (d->node_child[2 * i] == 0 || d->node_child[2 * i + 1] <= 0) {
+      return fail(RT_ERR_INVALID, "node %d has a bad child index", i);
+    }
+    return RT_OK;
+  };
+  const int TOP_LEVELS = 10;
+  int depth = 0;
+  if ((rc = check_node(0))) return rc;
+  level[0] = 0;
+  std::vector<int> frontier{0}, deep_roots;
+  for (int lv = 0; !frontier.empty(); ++lv) {
+    std::vector<int> next;
+    for (int i : frontier) {
+      depth = std::max(depth, lv);
+      if (is_leaf(i)) continue;
+      if (lv >= TOP_LEVELS) { deep_roots.push_back(i); continue; }
+      dev_index[i] = (int)order.size(); order.push_back(i);
+      for (int k = 0; k < 2; ++k) {
+        int c = d->node_child[2 * i + k];
+        if ((rc = check_node(c))) return rc;
+        level[c] = lv + 1; next.push_back(c);
+      }
+    }
+    frontier.swap(next);
+  }
+  for (int r : deep_roots) {   // depth-first (pre-order) below the top levels
+    std::vector<int> stk{r};
+    while (!stk.empty()) {
+      int i = stk.back(); stk.pop_back();
+      depth = std::max(depth, level[i]);
+      if (is_leaf(i)) continue;
+      dev_index[i] = (int)order.size(); order.push_back(i);
+      for (int k = 1; k >= 0; --k) {
+        int c = d->node_child[2 * i + k];
+        if ((rc = check_node(c))) return rc;
+        level[c] = level[i] + 1; stk.push_back(c);
+      }
+    }
+  }
+  if (depth > 60) return fail(RT_ERR_UNSUPPORTED, "BVH depth %d exceeds the traversal stack limit (60)", depth);
+
+  auto *s = new rt_scene();
+  s->device = g_ctx.device;
+  s->depth = depth;
+  s->n_internal = (int)order.size();
+
+  // ---- materials: dense table, index 0 = defaultMaterial (Rendering/Material.hs:25-35)
+  std::vector<DMaterial> mats(1 + d->n_materials);
+  auto set_mat = [](DMaterial &m, const rt_material *src) {
+    std::memset(&m, 0, sizeof m);
+    if (!src) { m.diffuse[0] = m.diffuse[1] = m.diffuse[2] = 1.0; return; }
+    for (int k = 0; k < 3; ++k) { m.diffuse[k] = src->diffuse[k]; m.emission[k] = (src->flags & RT_MAT_HAS_EMISSION) ? src->emission[k] : 0.0; }
+    const bool trans1 = (src->flags & RT_MAT_HAS_TRANSMISSION) && src->transmission == 1.0;
+    m.ior = src->ior;
+    if (trans1) m.flags |= DMAT_NO_ATTEN;
+    if (trans1 && (src->flags & RT_MAT_HAS_IOR)) m.flags |= DMAT_GLASS_DIR;
+    if ((src->flags & RT_MAT_HAS_SHININESS) && src->shininess > 100) m.flags |= DMAT_METAL;
+  };
+  set_mat(mats[0], nullptr);
+  for (int i = 0; i < d->n_materials; ++i) set_mat(mats[1 + i], &d->materials[i]);
+  auto mat_index = [&](int id) {   // M.lookup: the LAST entry with that key wins (M.fromList)
+    for (int i = d->n_materials - 1; i >= 0; --i) if (d->materials[i].id == id) return 1 + i;
+    return 0;
+  };
+  std::vector<int> mat_cache_id, mat_cache_ix;
+
+  // ---- primitives (leaf order is kept: it decides ties) + the FP64 leaf boxes planes need
+  std::vector<DPrim> prims(np);
+  std::vector<int32_t> pids(np);
+  std::vector<double> plane_boxes;
+  double maxabs = 0;
+  for (int i = 0; i < np; ++i) {
+    const double *src = d->prim_data + 9 * (size_t)i;
+    DPrim &P = prims[i];
+    std::memset(&P, 0, sizeof P);
+    int kind = d->prim_kind[i];
+    if (kind < RT_PRIM_TRIANGLE || kind > RT_PRIM_PLANE) { delete s; return fail(RT_ERR_INVALID, "primitive %d has unknown kind %d", i, kind); }
+    if (kind == RT_PRIM_TRIANGLE) {
+      for (int k = 0; k < 3; ++k) {
+        P.d[k] = src[k];
+        P.d[3 + k] = src[3 + k] - src[k];   // e1 = p1 - p0, Triangle.hs:32
+        P.d[6 + k] = src[6 + k] - src[k];   // e2 = p2 - p0, Triangle.hs:33
+      }
+    } else {
+      for (int k = 0; k < 9; ++k) P.d[k] = src[k];
+      if (kind == RT_PRIM_PLANE) P.d[6] = -1.0;
+    }
+    P.kind = (uint32_t)kind;
+    int mid = d->prim_material[i], mix = -1;
+    for (size_t k = 0; k < mat_cache_id.size(); ++k) if (mat_cache_id[k] == mid) { mix = mat_cache_ix[k]; break; }
+    if (mix < 0) { mix = mat_index(mid); mat_cache_id.push_back(mid); mat_cache_ix.push_back(mix); }
+    P.mat = mix;
+    pids[i] = d->prim_id ? d->prim_id[i] : i;
+  }
+  // leaves: mark the last primitive, give planes their leaf box
+  std::vector<char> in_leaf(np, 0);
+  for (int i = 0; i < nn; ++i) {
+    if (!seen[i] || !is_leaf(i)) continue;
+    long first = -1L - d->node_child[2 * i], cnt = d->node_child[2 * i + 1];
+    prims[first + cnt - 1].kind |= DPRIM_LAST;
+    for (long k = first; k < first + cnt; ++k) {
+      if (in_leaf[k]) { delete s; return fail(RT_ERR_INVALID, "primitive %ld belongs to two leaves", k); }
+      in_leaf[k] = 1;
+      if ((prims[k].kind & DPRIM_KIND_MASK) == RT_PRIM_PLANE && i != 0) {   // the root's own box is never tested (BVH.hs:123)
+        prims[k].d[6] = (double)(plane_boxes.size() / 6);
+        for (int q = 0; q < 6; ++q) plane_boxes.push_back(d->node_bounds[6 * (size_t)i + q]);
+      }
+    }
+  }
+  for (int q = 0; q < 6; ++q) maxabs = std::max(maxabs, std::fabs(d->node_bounds[q]));
+
+  // ---- internal nodes: children's boxes, FP64 as given and FP32 rounded outward
+  const int ni = std::max(1, s->n_internal);
+  std::vector<DNode<float>> n32(ni);
+  s->h_nodes64.assign(ni, DNode<double>());
+  std::memset(n32.data(), 0, ni * sizeof(DNode<float>));
+  std::memset(s->h_nodes64.data(), 0, ni * sizeof(DNode<double>));
+  auto ref_of = [&](int child) -> int32_t { return is_leaf(child) ? d->node_child[2 * child] : dev_index[child]; };   // leaf: -1-first == ~first
+  for (int k = 0; k < s->n_internal; ++k) {
+    int i = order[k];
+    for (int c = 0; c < 2; ++c) {
+      int child = d->node_child[2 * i + c];
+      const double *b = d->node_bounds + 6 * (size_t)child;
+      for (int q = 0; q < 3; ++q) {
+        s->h_nodes64[k].box[6 * c + q] = b[q];
+        s->h_nodes64[k].box[6 * c + 3 + q] = b[3 + q];
+        n32[k].box[6 * c + q] = f32_down(b[q]);
+        n32[k].box[6 * c + 3 + q] = f32_up(b[3 + q]);
+      }
+      s->h_nodes64[k].ref[c] = n32[k].ref[c] = ref_of(child);
+    }
+  }
+
+  std::vector<DLight> lights(std::max(1, d->n_lights));
+  std::memset(lights.data(), 0, lights.size() * sizeof(DLight));
+  for (int i = 0; i < d->n_lights; ++i) {
+    if (d->lights[i].kind != RT_LIGHT_POINT && d->lights[i].kind != RT_LIGHT_DIRECTIONAL) { delete s; return fail(RT_ERR_INVALID, "light %d has unknown kind", i); }
+    for (int k = 0; k < 3; ++k) { lights[i].vec[k] = d->lights[i].vec[k]; lights[i].intensity[k] = d->lights[i].intensity[k]; }
+    lights[i].kind = d->lights[i].kind;
+  }
+
+#define UP(call) do { if ((rc = (call))) { rt_scene_destroy(s); return rc; } } while (0)
+  UP(dev_upload(&s->d_nodes32, n32.data(), (size_t)ni));
+  UP(dev_upload(&s->d_prims, prims.data(), (size_t)np));
+  UP(dev_upload(&s->d_prim_ids, pids.data(), (size_t)np));
+  UP(dev_upload(&s->d_mats, mats.data(), mats.size()));
+  UP(dev_upload(&s->d_lights, lights.data(), lights.size()));
+  UP(dev_upload(&s->d_plane_boxes, plane_boxes.data(), plane_boxes.size()));
+  if (d->sky_format != RT_SKY_NONE) {
+    size_t bytes = (size_t)d->sky_width * d->sky_height * 3 * (d->sky_format == RT_SKY_RGB8 ? 1 : 4);
+    uint8_t *p = nullptr;
+    UP(dev_upload(&p, (const uint8_t *)d->sky_pixels, bytes));
+    s->d_sky = p;
+  }
+  uint32_t zero = 0;
+  UP(dev_upload(&s->d_counter, &zero, 1));
+  unsigned long long zs[STAT_COUNT] = {0};
+  UP(dev_upload(&s->d_stats, zs, STAT_COUNT));
+#undef UP
+  if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
+
+  KScene &k = s->ks;
+  k.nodes = s->d_nodes32; k.prims = s->d_prims; k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
+  k.plane_boxes = s->d_plane_boxes; k.sky = s->d_sky;
+  k.root_ref = is_leaf(0) ? d->node_child[0] : 0;
+  k.n_lights = d->n_lights;
+  k.bg_kind = d->bg_kind; k.sky_format = d->sky_format; k.sky_w = d->sky_width; k.sky_h = d->sky_height;
+  for (int q = 0; q < 3; ++q) { k.bg1[q] = d->bg_color1[q]; k.bg2[q] = d->bg_color2[q]; }
+  k.rscene = f32_up(maxabs);
+  if (d->bg_kind != RT_BG_GRADIENT && d->bg_kind != RT_BG_SOLID) { rt_scene_destroy(s); return fail(RT_ERR_INVALID, "unknown background kind"); }
+  *out = s;
+  return RT_OK;
+}
+
+
+int rt_tile_count(int32_t W, int32_t H, int32_t rank, int32_t world) {
+  if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad tile query");
+  int tx = tiles_x_of(W), ty = tiles_y_of(H), n = 0;
+  for (int y = 0; y < ty; ++y)
+    for (int x = 0; x < tx; ++x) n += ((x + y) % world) == rank;
+  return n;
+}
+
+int rt_tile_list(int32_t W, int32_t H, int32_t rank, int32_t world, int32_t *tiles) {
+  if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world || !tiles) return fail(RT_ERR_INVALID, "bad tile query");
+  int tx = tiles_x_of(W), ty = tiles_y_of(H), n = 0;
+  for (int y = 0; y < ty; ++y)
+    for (int x = 0; x < tx; ++x)
+      if (((x + y) % world) == rank) tiles[n++] = y * tx + x;
+  return n;
+}
+
+}  // extern "C"
+
+static int check_frame(const rt_scene *s, const rt_camera *cam, const rt_params *p) {
+  if (!s || !cam || !p) return fail(RT_ERR_INVALID, "null argument");
+  if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_bounces < 0)
+    return fail(RT_ERR_INVALID, "bad image/raytracer settings");
+  if ((long long)p->width * p->height >= (1LL << 31)) return fail(RT_ERR_UNSUPPORTED, "image too large");
+  if (p->rr_start_bounce != 0) return fail(RT_ERR_UNSUPPORTED, "Russian roulette is not in the reference (Config.hs:57) and not implemented");
+  if (p->box_precision != 0 && p->box_precision != 1) return fail(RT_ERR_INVALID, "box_precision must be 0 or 1");
+  return RT_OK;
+}
+
+static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
+  if (s->tl_w == W && s->tl_h == H && s->tl_rank == rank && s->tl_world == world) return RT_OK;
+  int n = rt_tile_count(W, H, rank, world);
+  if (n < 0) return n;
+  std::vector<int32_t> t(std::max(1, n));
+  rt_tile_list(W, H, rank, world, t.data());
+  (void)hipFree(s->d_tiles); s->d_tiles = nullptr;
+  int rc = dev_upload(&s->d_tiles, t.data(), t.size());
+  if (rc) return rc;
+  s->tl_w = W; s->tl_h = H; s->tl_rank = rank; s->tl_world = world; s->tl_n = n;
+  return RT_OK;
+}
+
+template <typename BT, bool STATS>
+static int launch_kernel(rt_scene *s, const KFrame &fr, hipStream_t stream) {
+  const int threads = 256;
+  const size_t lds = (size_t)(threads / 64) * fr.stack_depth * 64 * sizeof(uint2);
+  if (lds > 160 * 1024) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
+  auto kern = k_render_tiles<BT, STATS>;
+  if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+  per_cu = std::max(1, per_cu);
+  const int want = (fr.n_tiles + 3) / 4;
+  const int grid = std::max(1, std::min(want, g_ctx.n_cu * per_cu));
+  HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
+  if (STATS) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
+  KScene ks = s->ks;
+  if (sizeof(BT) == 8) ks.nodes = s->d_nodes64;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, ks, fr);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+static int launch_render(rt_scene *s, const rt_camera *cam, const rt_params *p, int rank, int world, bool packed,
+                         double *d_color, double *d_radiance, int32_t *d_primid, hipStream_t stream) {
+  int rc;
+  KFrame fr{};
+  fr.cam = *cam;
+  fr.W = p->width; fr.H = p->height; fr.spp = p->samples_per_pixel; fr.aa = p->antialiasing != 0; fr.maxb = p->max_bounces;
+  fr.exposure = p->exposure; fr.gamma = p->gamma;
+  fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
+  fr.tiles_x = tiles_x_of(p->width);
+  if (world > 1 || packed) {
+    if ((rc = ensure_tiles(s, p->width, p->height, rank, world))) return rc;
+    fr.tiles = s->d_tiles; fr.n_tiles = s->tl_n;
+  } else {
+    fr.tiles = nullptr; fr.n_tiles = fr.tiles_x * tiles_y_of(p->height);
+  }
+  fr.packed = packed ? 1 : 0;
+  fr.out_color = d_color; fr.out_radiance = d_radiance; fr.out_primid = d_primid;
+  fr.tile_counter = s->d_counter; fr.stats = s->d_stats;
+  fr.stack_depth = std::max(1, s->depth) + 1;
+  if (fr.n_tiles == 0) return RT_OK;
+  if (p->box_precision == 1 && !s->d_nodes64) {
+    if ((rc = dev_upload(&s->d_nodes64, s->h_nodes64.data(), s->h_nodes64.size()))) return rc;
+  }
+  const bool st = p->collect_stats != 0;
+  if (p->box_precision == 1) return st ? launch_kernel<double, true>(s, fr, stream) : launch_kernel<double, false>(s, fr, stream);
+  return st ? launch_kernel<float, true>(s, fr, stream) : launch_kernel<float, false>(s, fr, stream);
+}
+
+static int read_stats(rt_scene *s, rt_stats *st) {
+  unsigned long long h[STAT_COUNT];
+  HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  st->rays_closest = h[STAT_CLOSEST]; st->rays_shadow = h[STAT_SHADOW]; st->nodes_visited = h[STAT_NODES];
+  st->tri_tests = h[STAT_TRI]; st->sphere_tests = h[STAT_SPHERE]; st->plane_tests = h[STAT_PLANE]; st->shaded_hits = h[STAT_SHADED];
+  return RT_OK;
+}
+
+extern "C" {
+
+int rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
+  int rc = check_frame(s, cam, p);
+  if (rc) return rc;
+  if (!out) return fail(RT_ERR_INVALID, "null output");
+  auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t npx = (size_t)p->width * p->height;
+  if (npx > s->cap_px) {
+    (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
+    s->d_color = s->d_radiance = nullptr; s->d_primid = nullptr; s->d_rgb8 = nullptr; s->cap_px = 0;
+    if (hipMalloc((void **)&s->d_color, npx * 24) != hipSuccess || hipMalloc((void **)&s->d_radiance, npx * 24) != hipSuccess ||
+        hipMalloc((void **)&s->d_primid, npx * 4) != hipSuccess || hipMalloc((void **)&s->d_rgb8, npx * 3) != hipSuccess)
+      return fail(RT_ERR_OOM, "output buffers for %zu pixels", npx);
+    s->cap_px = npx;
+  }
+  hipStream_t stream = nullptr;
+  HIP_TRY(hipEventRecord(s->ev0, stream));
+  rc = launch_render(s, cam, p, 0, 1, false, s->d_color, out->radiance ? s->d_radiance : nullptr,
+                     out->prim_id ? s->d_primid : nullptr, stream);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(s->ev1, stream));
+  if (out->rgb8) {
+    const long long n = (long long)npx * 3;
+    hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s->d_color, s->d_rgb8, n);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (out->color) HIP_TRY(hipMemcpy(out->color, s->d_color, npx * 24, hipMemcpyDeviceToHost));
+  if (out->radiance) HIP_TRY(hipMemcpy(out->radiance, s->d_radiance, npx * 24, hipMemcpyDeviceToHost));
+  if (out->prim_id) HIP_TRY(hipMemcpy(out->prim_id, s->d_primid, npx * 4, hipMemcpyDeviceToHost));
+  if (out->rgb8) HIP_TRY(hipMemcpy(out->rgb8, s->d_rgb8, npx * 3, hipMemcpyDeviceToHost));
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->ms_render = ms;
+    stats->paths = (uint64_t)npx * p->samples_per_pixel;
+    if (p->collect_stats && (rc = read_stats(s, stats))) return rc;
+    stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return RT_OK;
+}
+
+int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p, int32_t rank, int32_t world,
+                           void *d_color, void *d_radiance, void *d_prim_id, void *stream, rt_stats *stats) {
+  int rc = check_frame(s, cam, p);
+  if (rc) return rc;
+  if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad rank/world");
+  if (!d_color && !d_radiance && !d_prim_id) return fail(RT_ERR_INVALID, "no output buffer");
+  HIP_TRY(hipSetDevice(s->device));
+  rc = launch_render(s, cam, p, rank, world, true, (double *)d_color, (double *)d_radiance, (int32_t *)d_prim_id, (hipStream_t)stream);
+  if (rc) return rc;
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->paths = (uint64_t)s->tl_n * 64 * p->samples_per_pixel;
+    if (p->collect_stats) {
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      if ((rc = read_stats(s, stats))) return rc;
+    }
+  }
+  return RT_OK;
+}
+
+int rt_untile_device(int32_t W, int32_t H, int32_t rank, int32_t world, const void *d_packed, void *d_image,
+                     int32_t n_comp, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!d_packed || !d_image || n_comp <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
+  int n = rt_tile_count(W, H, rank, world);
+  if (n < 0) return n;
+  if (n == 0) return RT_OK;
+  std::vector<int32_t> t(n);
+  rt_tile_list(W, H, rank, world, t.data());
+  int32_t *d_t = nullptr;
+  HIP_TRY(hipMallocAsync((void **)&d_t, n * sizeof(int32_t), (hipStream_t)stream));
+  HIP_TRY(hipMemcpyAsync(d_t, t.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // t is a local: the copy must finish before it dies
+  const size_t slots = (size_t)n * 64;
+  hipLaunchKernelGGL(k_untile, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_t, n, tiles_x_of(W), W, H, n_comp, (const double *)d_packed, (double *)d_image);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipFreeAsync(d_t, (hipStream_t)stream));
+  return RT_OK;
+}
+
+int rt_quantize_device(const void *d_color, void *d_rgb8, int64_t n_values, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!d_color || !d_rgb8 || n_values < 0) return fail(RT_ERR_INVALID, "bad quantize arguments");
+  if (n_values == 0) return RT_OK;
+  hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const double *)d_color, (uint8_t *)d_rgb8, (long long)n_values);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
+}  // extern "C"
