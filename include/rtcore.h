@@ -146,7 +146,7 @@ typedef struct rt_output {
   double  *radiance;   /* 3*W*H  mean linear radiance  = averageColor, RenderWorker.hs:111-114 */
   double  *color;      /* 3*W*H  after toneMap + gammaCorrect = what pixelColor returns, RenderWorker.hs:76-82 */
   uint8_t *rgb8;       /* 3*W*H  truncate(c*255.999), RenderWorker.hs:108-109 (clamped to 0..255) */
-  int32_t *prim_id;    /* W*H    prim_id of the first sample's primary hit, -1 = miss */
+  int32_t *prim_id;    /* W*H    prim_id of the first sample's primary hit, -1 = miss (or max_bounces = 0: nothing traced) */
 } rt_output;
 
 typedef struct rt_stats {

@@ -660,9 +660,9 @@ int orc_render(const orc_scene *o, const rt_camera *cam, const rt_params *prm,
         for (int sIdx = 0; sIdx < spp; ++sIdx) {                           // replicateM spp, :78
           key.sample = (uint32_t)sIdx;
           Ray ray = generateRay(*cam, i, rowIdx, W, H, prm->antialiasing != 0, key);   // :102
-          if (sIdx == 0 && prim_id) {
+          if (sIdx == 0 && prim_id) {   // id of the first traced ray's hit; nothing is traced when maxBounces = 0
             HitRecord r0;
-            bool h = hitBVH(s.bvh.get(), ray, {0.001, 10000}, r0, nullptr);
+            bool h = prm->max_bounces > 0 && hitBVH(s.bvh.get(), ray, {0.001, 10000}, r0, nullptr);
             prim_id[(size_t)j * W + i] = h ? r0.primId : -1;
           }
           V3 col = traceLoop(s, ray, ray, prm->max_bounces, V3{1, 1, 1}, key, 0, c);   // :106, Trace.hs:20
