@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — the BASELINE.json metric on MI355X: Mrays/s and frame time of the per-pixel ray<->scene
+hot path on the 63,432-triangle scene at 1920x1080, 100 spp (config C4), N = 1/2/4/8 GPUs.
+
+One step = one frame: every rank renders its interleaved 8x8 tiles from its HBM-resident scene copy,
+then the packed framebuffers are gathered on rank 0 over RCCL and un-tiled (raytracer_amd/dist.py).
+A ray = one BVH query (primary/bounce closest-hit + shadow any-hit), counted on the device by the
+stats variant of the kernel in an untimed pass (counts are deterministic for a seed).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NODE_BYTES = 64      # DNode<float>: both child boxes (FP32, conservative) + 2 refs
+PRIM_BYTES = 80      # DPrim: 9 doubles + material + kind
+MAT_BYTES = 64       # DMaterial fetched per shaded hit
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=100)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import api, scenes
+    from raytracer_amd import dist as rdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    mk = {"c4": scenes.c4_blob63k, "c3": scenes.c3_blob988, "c2": scenes.c2_spheres, "c5": scenes.c5_multi}[args.workload]
+    spec = mk(width=args.width, height=args.height, spp=args.spp)
+    W, H = spec.width, spec.height
+    t0 = time.time()
+    scene = api.GpuScene(spec, n_threads=8, device=local_rank)     # BVH build (host mirror) + upload to HBM
+    t_setup = time.time() - t0
+
+    n_local = len(rdist.tile_list_host(W, H, rank, world))
+    n_max = rdist.max_tiles(W, H, world)
+    packed = torch.zeros((n_max * 64, 3), dtype=torch.float64, device=dev)
+    image = torch.empty((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
+    bufs = [torch.empty_like(packed) for _ in range(world)] if (rank == 0 and world > 1) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- untimed counting pass: rays / nodes / primitive tests of this rank's share (deterministic per seed)
+    st = scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream, collect_stats=1)
+    torch.cuda.synchronize()
+    cnt = torch.tensor([st.rays_closest, st.rays_shadow, st.nodes_visited, st.tri_tests, st.sphere_tests, st.plane_tests,
+                        st.shaded_hits, st.paths], dtype=torch.int64, device=dev)
+    my_cnt = cnt.clone()
+    if world > 1:
+        dist.all_reduce(cnt)
+    tot = [int(x) for x in cnt.tolist()]
+    rays_total = tot[0] + tot[1]
+    mine = [int(x) for x in my_cnt.tolist()]
+    my_alg_bytes = NODE_BYTES * mine[2] + PRIM_BYTES * (mine[3] + mine[4] + mine[5]) + MAT_BYTES * mine[6]
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream)
+        if ev is not None:
+            ev[1].record()
+        img = rdist.gather_frame(packed, W, H, rank, world, image=image, gather_buffers=bufs)
+        if rank == 0:
+            from raytracer_amd import _ffi as F
+            F.check(F.core().rt_quantize_device(C.c_void_p(img.data_ptr()), C.c_void_p(rgb8.data_ptr()), 3 * W * H, C.c_void_p(stream)))
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))    # HIP events on the launch stream
+
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_total / (ms_per_step * 1e-3) / 1e6
+
+    if rank == 0:
+        achieved = my_alg_bytes / (kernel_ms * 1e-3) / 1e9        # rank 0's kernel: algorithmic GB/s
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured HBM bytes per launch (rocprofv3 --pmc), if committed
+        if os.path.exists(tf):
+            try:
+                rec = json.load(open(tf)).get(f"{args.workload}_{W}x{H}_spp{spec.spp}_n{world}")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s + frame time, 63k-tri monkey 1080p AA-100, at 1/2/4/8 MI355X",
+            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{spec.name}: {spec.n_triangles()} triangles, {W}x{H}, {spec.spp} spp, maxBounces {spec.max_bounces}, "
+                                   f"leafThreshold {spec.leaf_threshold}, bvhMaxDepth {spec.bvh_max_depth}, 1 point light",
+                       "parallelism": f"tiles{world}", "rays_per_frame": rays_total, "paths_per_frame": tot[7],
+                       "frame_time_s": round(ms_per_step * 1e-3, 5), "kernel_ms": round(kernel_ms_max, 3),
+                       "setup_s": round(t_setup, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_render_tiles<float,false>", "kernel_ms": round(kernel_ms, 3),
+                         "algorithmic_bytes_per_launch": my_alg_bytes,
+                         "bytes_per_ray": round(my_alg_bytes / max(1, mine[0] + mine[1]), 1),
+                         "nodes_per_ray": round(mine[2] / max(1, mine[0] + mine[1]), 2),
+                         "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / max(1, mine[0] + mine[1]), 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    scene.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(spec, threads):
+    """The oracle (a C++ port of the reference's algorithm, oracle/oracle.cpp) timed on the host cores on
+    a bounded sample of the SAME workload: every 27th row of the frame at full spp."""
+    from oracle import oracle as O
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    o = O.OracleScene(spec)
+    stride = 27 if spec.height >= 270 else 1
+    t0 = time.perf_counter()
+    _, cnt = o.render(rows=(stride // 2, spec.height), row_stride=stride, n_threads=threads, counters=True, want_ids=False)
+    dt = time.perf_counter() - t0
+    o.close()
+    rays = cnt["rays_closest"] + cnt["rays_shadow"]
+    rows = len(range(stride // 2, spec.height, stride))
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{rows} of {spec.height} rows (every {stride}th) x {spec.width} px x {spec.spp} spp = {rays} rays in {dt:.2f} s; "
+                      f"full frame extrapolates to {dt * spec.height / rows:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -636,21 +636,21 @@ struct orc_counters {
 };
 
 // The render driver: worker/renderRow/pixelColor/samplePixel, Rendering/RenderWorker.hs:53-114,
-// rows [row0,row1) of the FILE (row j of the file is rowIdx = H-1-j, :66) over `n_threads` threads
+// rows row0, row0+row_stride, ... < row1 of the FILE (row j of the file is rowIdx = H-1-j, :66) over `n_threads` threads
 // pulling rows from a shared counter (the TQueue of ImageGenerator.hs:64-71).
 // Outputs are full-frame sized (3*W*H etc.); only the requested rows are written.
 int orc_render(const orc_scene *o, const rt_camera *cam, const rt_params *prm,
-               int32_t row0, int32_t row1, int32_t n_threads,
+               int32_t row0, int32_t row1, int32_t row_stride, int32_t n_threads,
                double *radiance, double *color, uint8_t *rgb8, int32_t *prim_id, orc_counters *counters) {
   const Scene &s = o->s;
   const int W = prm->width, H = prm->height, spp = prm->samples_per_pixel;
-  if (W <= 0 || H <= 0 || spp <= 0 || row0 < 0 || row1 > H) return RT_ERR_INVALID;
-  std::atomic<int> nextRow(row0);
+  if (W <= 0 || H <= 0 || spp <= 0 || row0 < 0 || row1 > H || row_stride < 1) return RT_ERR_INVALID;
+  std::atomic<int> nextRow(0);
   std::vector<Counters> perThread((size_t)std::max(1, n_threads));
   auto work = [&](int tid) {
     Counters *c = counters ? &perThread[tid] : nullptr;
     for (;;) {
-      int j = nextRow.fetch_add(1);                                        // tryReadTQueue, RenderWorker.hs:55
+      int j = row0 + row_stride * nextRow.fetch_add(1);                    // tryReadTQueue, RenderWorker.hs:55
       if (j >= row1) break;
       int rowIdx = H - 1 - j;                                              // :66
       for (int i = 0; i < W; ++i) {                                        // :67

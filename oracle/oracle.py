@@ -44,7 +44,7 @@ def lib():
         L.orc_bvh_export.argtypes = [C.c_void_p, dp, ip, ip, dp, ip, ip]
         L.orc_default_camera.argtypes = [dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(F.rt_camera)]
         L.orc_render.restype = C.c_int
-        L.orc_render.argtypes = [C.c_void_p, C.POINTER(F.rt_camera), C.POINTER(F.rt_params), C.c_int32, C.c_int32, C.c_int32,
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(F.rt_camera), C.POINTER(F.rt_params), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  dp, dp, F.c_uint8_p, ip, C.POINTER(orc_counters)]
         L.orc_hit_aabb.restype = C.c_int
         L.orc_hit_aabb.argtypes = [dp, dp, dp, dp, C.c_double, C.c_double, dp]
@@ -124,8 +124,8 @@ class OracleScene:
                              _ip(a["prim_material"]), _ip(a["prim_id"]))
         return a
 
-    def render(self, rows=None, n_threads=8, counters=False, camera=None, want_ids=True, **param_over):
-        """Renders file rows [rows[0], rows[1]) (default: all).  Returns dict of full-frame arrays
+    def render(self, rows=None, n_threads=8, counters=False, camera=None, want_ids=True, row_stride=1, **param_over):
+        """Renders file rows rows[0], rows[0]+row_stride, ... < rows[1] (default: all).  Returns dict of full-frame arrays
         (unrendered rows are NaN / -2) and, with counters=True, the traversal counters."""
         p = make_params(self.spec, **param_over)
         W, H = p.width, p.height
@@ -134,7 +134,7 @@ class OracleScene:
         rgb = np.zeros((H, W, 3), np.uint8); ids = np.full((H, W), -2, np.int32)
         cnt = orc_counters()
         cam = camera if camera is not None else self.camera
-        rc = lib().orc_render(self._h, C.byref(cam), C.byref(p), r0, r1, n_threads, _dp(rad), _dp(col),
+        rc = lib().orc_render(self._h, C.byref(cam), C.byref(p), r0, r1, row_stride, n_threads, _dp(rad), _dp(col),
                               rgb.ctypes.data_as(F.c_uint8_p), _ip(ids) if want_ids else None,
                               C.byref(cnt) if counters else None)
         if rc != 0:

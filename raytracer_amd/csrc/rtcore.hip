@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -423,6 +424,28 @@ static int read_stats(rt_scene *s, rt_stats *st) {
   return RT_OK;
 }
 
+// device-resident tile lists for rt_untile_device, created once per (device, W, H, rank, world) and kept
+struct TileCacheEntry { int device, W, H, rank, world, n; int32_t *d_tiles; };
+static std::vector<TileCacheEntry> g_tile_cache;
+static std::mutex g_tile_mu;
+static int cached_tiles(int W, int H, int rank, int world, const int32_t **d_tiles, int *n) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> g(g_tile_mu);
+  for (auto &e : g_tile_cache)
+    if (e.device == dev && e.W == W && e.H == H && e.rank == rank && e.world == world) { *d_tiles = e.d_tiles; *n = e.n; return RT_OK; }
+  int cnt = rt_tile_count(W, H, rank, world);
+  if (cnt < 0) return cnt;
+  std::vector<int32_t> t(std::max(1, cnt));
+  rt_tile_list(W, H, rank, world, t.data());
+  int32_t *d = nullptr;
+  int rc = dev_upload(&d, t.data(), t.size());   // synchronous copy: t may die afterwards
+  if (rc) return rc;
+  g_tile_cache.push_back({dev, W, H, rank, world, cnt, d});
+  *d_tiles = d; *n = cnt;
+  return RT_OK;
+}
+
 extern "C" {
 
 int rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
@@ -493,20 +516,14 @@ int rt_untile_device(int32_t W, int32_t H, int32_t rank, int32_t world, const vo
   int rc = ensure_init();
   if (rc) return rc;
   if (!d_packed || !d_image || n_comp <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
-  int n = rt_tile_count(W, H, rank, world);
-  if (n < 0) return n;
+  int n = 0;
+  const int32_t *d_t = nullptr;
+  if ((rc = cached_tiles(W, H, rank, world, &d_t, &n))) return rc;
   if (n == 0) return RT_OK;
-  std::vector<int32_t> t(n);
-  rt_tile_list(W, H, rank, world, t.data());
-  int32_t *d_t = nullptr;
-  HIP_TRY(hipMallocAsync((void **)&d_t, n * sizeof(int32_t), (hipStream_t)stream));
-  HIP_TRY(hipMemcpyAsync(d_t, t.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // t is a local: the copy must finish before it dies
   const size_t slots = (size_t)n * 64;
   hipLaunchKernelGGL(k_untile, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      d_t, n, tiles_x_of(W), W, H, n_comp, (const double *)d_packed, (double *)d_image);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipFreeAsync(d_t, (hipStream_t)stream));
   return RT_OK;
 }
 
