@@ -1,0 +1,158 @@
+"""Host mirror of loadConfig / parseSceneObjects / parseObj / parseMaterial (librthost) on files written in the
+reference's schema: the assembled `allObjects`, material ids and lights must equal the in-memory SceneSpec, and
+the reference's parsing quirks must be reproduced."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import _ffi as F
+from raytracer_amd import api, scenes
+
+
+def load(path):
+    h = C.c_void_p()
+    F.check(F.host().rth_config_load(str(path).encode(), C.byref(h)), "host")
+    v = F.rth_config_view()
+    F.check(F.host().rth_config_get(h, C.byref(v)), "host")
+    n = v.n_objs
+    res = {"view": v, "handle": h,
+           "kind": np.ctypeslib.as_array(v.obj_kind, shape=(n,)).copy() if n else np.zeros(0, np.int32),
+           "data": np.ctypeslib.as_array(v.obj_data, shape=(n * 9,)).reshape(n, 9).copy() if n else np.zeros((0, 9)),
+           "material": np.ctypeslib.as_array(v.obj_material, shape=(n,)).copy() if n else np.zeros(0, np.int32)}
+    return res
+
+
+@pytest.mark.parametrize("mk", [scenes.c1_testing, scenes.c2_spheres, scenes.c3_blob988])
+def test_roundtrip_equals_scenespec(tmp_path, mk):
+    spec = mk()
+    jp = scenes.write_reference_files(spec, str(tmp_path))
+    r = load(jp)
+    k, d, m = spec.all_objects()
+    assert np.array_equal(r["kind"], k) and np.array_equal(r["material"], m)
+    assert np.array_equal(r["data"], d)                     # repr() round-trips doubles exactly
+    v = r["view"]
+    assert (v.params.width, v.params.height, v.params.samples_per_pixel, v.params.max_bounces) == (spec.width, spec.height, spec.spp, spec.max_bounces)
+    assert v.params.antialiasing == int(spec.antialiasing) and v.params.gamma == spec.gamma and v.params.exposure == spec.exposure
+    assert (v.bvh_max_depth, v.leaf_threshold, v.n_triangles) == (spec.bvh_max_depth, spec.leaf_threshold, spec.n_triangles())
+    assert bytes(v.camera) == bytes(api.default_camera(spec.camera, spec.width / spec.height))
+    mats, nm = api.make_materials(spec)
+    assert v.n_materials == nm
+    for i in range(nm):
+        assert bytes(v.materials[i]) == bytes(mats[i])
+    lights, nl = api.make_lights(spec)
+    assert v.n_lights == nl and all(bytes(v.lights[i]) == bytes(lights[i]) for i in range(nl))
+    F.host().rth_config_destroy(r["handle"])
+
+
+def base_config(scene):
+    return {"image": {"width": 8, "height": 4, "samplesPerPixel": 1, "antialiasing": False, "gamma": 1.0, "exposure": 1.0},
+            "background": {"tag": "SolidColor", "color": [1, 1, 1]},
+            "camera": {"lookFrom": [0, 0, 5], "lookAt": [0, 0, 0], "vUp": [0, 1, 0], "vfov": 60.0, "aperture": 0.0, "focusDist": 1.0},
+            "raytracer": {"maxBounces": 2, "useBVH": True, "bvhMaxDepth": 8, "leafThreshold": 2},
+            "scene": scene}
+
+
+def test_obj_and_mtl_quirks(tmp_path):
+    (tmp_path / "m.mtl").write_text(
+        "newmtl zeta\nKd 0.1 0.2 0.3\nNs 250\n"
+        "newmtl alpha\nKd 1 0 0\nKe 2 2 2\nNi 1.45\nillum 7\n"
+        "newmtl beta\nNi 1.0\nillum 9\n")
+    (tmp_path / "a.obj").write_text(
+        "mtllib m.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n"
+        "usemtl alpha\nf 1/1/1 2/2/1 3/3/1\n"        # 3-gon: emitted as (v0, v2, v1)
+        "usemtl zeta\nf 1 2 3 4\n"                    # n-gon: fan (v0, vi, vi+1), un-flipped
+        "usemtl unknown\nf 1 3 4\n")                  # unknown material name -> id 0
+    cfg = base_config({"materials": [["json", {"diffuseColor": [0.5, 0.5, 0.5]}]],
+                       "objFiles": [{"path": str(tmp_path / "a.obj"), "objposition": [10, 0, 0]}],
+                       "objects": [{"tag": "TriangleObj", "contents": [[0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1], "json"]},
+                                   {"tag": "SphereObj", "contents": [[0, 0, 0], 1.5, [1, 1, 1], None]},
+                                   {"tag": "PlaneObj", "contents": [[0, -1, 0], [0, 1, 0], [1, 1, 1], "beta"]}],
+                       "lights": [{"tag": "DirectionalLight", "direction": [0, -1, 0], "intensity": [1, 1, 1]}]})
+    jp = tmp_path / "c.json"
+    jp.write_text(json.dumps(cfg))
+    r = load(jp)
+    # allObjects = configTriangles ++ objTriangles ++ ALL config objects (the config triangle twice)
+    assert r["kind"].tolist() == [0, 0, 0, 0, 0, 0, 1, 2]
+    d = r["data"]
+    assert d[0].tolist() == [0, 0, 1, 1, 0, 1, 0, 1, 1]
+    assert d[1].tolist() == [10, 0, 0, 11, 1, 0, 11, 0, 0]          # (v0, v2, v1) + offset
+    assert d[2].tolist() == [10, 0, 0, 11, 0, 0, 11, 1, 0]          # fan, un-flipped
+    assert d[3].tolist() == [10, 0, 0, 11, 1, 0, 10, 1, 0]
+    assert d[6, :4].tolist() == [0, 0, 0, 1.5] and d[7, :6].tolist() == [0, -1, 0, 0, 1, 0]
+    # ids: JSON from 1; MTL from 0 in NAME order (alpha 0, beta 1, zeta 2); JSON shadows MTL on id clashes
+    assert r["material"].tolist() == [1, 0, 2, 2, 0, 1, 0, 1]
+    v = r["view"]
+    mats = {v.materials[i].id: v.materials[i] for i in range(v.n_materials)}
+    assert sorted(mats) == [0, 1, 2]
+    assert list(mats[1].diffuse) == [0.5, 0.5, 0.5]                 # id 1 is the JSON material, MTL "beta" is shadowed
+    a = mats[0]                                                     # alpha: illum 7 and Ni > 1 -> transmission 1
+    assert a.flags == (F.RT_MAT_HAS_EMISSION | F.RT_MAT_HAS_IOR | F.RT_MAT_HAS_TRANSMISSION) and a.transmission == 1.0 and a.ior == 1.45
+    z = mats[2]
+    assert z.flags == F.RT_MAT_HAS_SHININESS and z.shininess == 250 and list(z.diffuse) == [0.1, 0.2, 0.3]
+    assert v.n_triangles == 5 and v.n_lights == 1 and v.lights[0].kind == F.RT_LIGHT_DIRECTIONAL
+    F.host().rth_config_destroy(r["handle"])
+
+
+def test_errors_mirror_the_reference(tmp_path):
+    def fails(cfg_text, needle):
+        p = tmp_path / "bad.json"
+        p.write_text(cfg_text)
+        h = C.c_void_p()
+        rc = F.host().rth_config_load(str(p).encode(), C.byref(h))
+        assert rc == F.RT_ERR_INVALID
+        assert needle in F.host().rth_last_error().decode(), F.host().rth_last_error()
+
+    h = C.c_void_p()
+    assert F.host().rth_config_load(str(tmp_path / "missing.json").encode(), C.byref(h)) == F.RT_ERR_INVALID
+    assert "Config file not found" in F.host().rth_last_error().decode()          # Config.hs:132
+    fails("{", "Error parsing config file")
+    cfg = base_config({})
+    del cfg["image"]["gamma"]                                                      # every ImageSettings field is required
+    fails(json.dumps(cfg), "gamma")
+    cfg = base_config({"objects": [{"tag": "SphereObj", "contents": [[0, 0], 1.0, [1, 1, 1], None]}]})
+    fails(json.dumps(cfg), "Vec3 must contain exactly three valid numbers")        # Vec3.hs:44
+    (tmp_path / "bad.obj").write_text("v 0 0\nf 1 2 3\n")
+    cfg = base_config({"objFiles": [{"path": str(tmp_path / "bad.obj"), "objposition": [0, 0, 0]}]})
+    fails(json.dumps(cfg), "Invalid vertex format in .obj file")                   # Object.hs:40
+    (tmp_path / "bad2.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2\n")
+    cfg = base_config({"objFiles": [{"path": str(tmp_path / "bad2.obj"), "objposition": [0, 0, 0]}]})
+    fails(json.dumps(cfg), "Invalid face format in .obj file")                     # Object.hs:67
+    # optional scene fields may all be absent (Maybe): an empty scene parses, the BVH build then refuses it
+    p = tmp_path / "empty.json"
+    p.write_text(json.dumps(base_config({})))
+    r = load(p)
+    assert r["view"].n_objs == 0
+    F.host().rth_config_destroy(r["handle"])
+
+
+def test_ppm_body_is_byte_exact(tmp_path):
+    rgb = np.array([[[0, 5, 12], [100, 255, 99]], [[7, 70, 200], [1, 2, 3]]], np.uint8)
+    p = tmp_path / "o.ppm"
+    F.check(F.host().rth_write_ppm(str(p).encode(), 2, 2, rgb.ctypes.data_as(F.c_uint8_p)), "host")
+    # "P3\n" ++ show w ++ " " ++ show h ++ "\n255\n" ++ unlines (map showPixel ...)   ImageGenerator.hs:100, RenderWorker.hs:72,108
+    assert p.read_text() == "P3\n2 2\n255\n0 5 12\n100 255 99\n7 70 200\n1 2 3\n"
+    need = F.host().rth_format_ppm(2, 2, rgb.ctypes.data_as(F.c_uint8_p), None, 0)
+    assert need == len(p.read_text())
+
+
+def test_sky_loader(tmp_path):
+    # flat (non-RLE) Radiance file, 2x1: RGBE (128,64,32,129) -> (m+0.5)*2^(e-136)
+    hdr = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 2\n" + bytes([128, 64, 32, 129, 0, 0, 0, 0])
+    p = tmp_path / "s.hdr"
+    p.write_bytes(hdr)
+    fmt, w, h, px = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+    F.check(F.host().rth_sky_load(str(p).encode(), C.byref(fmt), C.byref(w), C.byref(h), C.byref(px)), "host")
+    a = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), shape=(6,)).copy()
+    F.host().rth_sky_free(px)
+    assert (fmt.value, w.value, h.value) == (F.RT_SKY_RGBF, 2, 1)
+    assert np.allclose(a, [128.5 / 128, 64.5 / 128, 32.5 / 128, 0, 0, 0])
+    q = tmp_path / "s.ppm"
+    q.write_bytes(b"P6\n2 1\n255\n" + bytes([1, 2, 3, 4, 5, 6]))
+    F.check(F.host().rth_sky_load(str(q).encode(), C.byref(fmt), C.byref(w), C.byref(h), C.byref(px)), "host")
+    b = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), shape=(6,)).copy()
+    F.host().rth_sky_free(px)
+    assert fmt.value == F.RT_SKY_RGB8 and b.tolist() == [1, 2, 3, 4, 5, 6]
