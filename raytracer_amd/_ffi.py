@@ -127,7 +127,8 @@ def core():
     """librtcore.so (HIP).  Raises OSError when it has not been built."""
     global _core
     if _core is None:
-        path = os.path.join(LIB_DIR, "librtcore.so")
+        # RTCORE_LIB: an alternative build of the SAME library (A/B runs of kernel variants, tools/ab.sh)
+        path = os.environ.get("RTCORE_LIB") or os.path.join(LIB_DIR, "librtcore.so")
         if not os.path.exists(path):
             raise OSError(f"{path} is missing: run `make core` (hipcc --offload-arch=gfx950); there is no fallback")
         _core = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), RTCORE_SYMBOLS)

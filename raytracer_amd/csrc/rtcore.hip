@@ -78,6 +78,8 @@ struct rt_scene {
   // per-launch scratch
   uint32_t *d_counter = nullptr;
   unsigned long long *d_stats = nullptr;
+  double *d_fscratch = nullptr;         // per resident wave: bounds of the pending clamp function (rt_kernel_v3.h)
+  size_t fscratch_waves = 0;
   // cached outputs of rt_render
   size_t cap_px = 0;
   double *d_color = nullptr, *d_radiance = nullptr;
@@ -116,7 +118,7 @@ void rt_scene_destroy(rt_scene *s) {
   if (!s) return;
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
   (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_sky);
-  (void)hipFree(s->d_counter); (void)hipFree(s->d_stats);
+  (void)hipFree(s->d_counter); (void)hipFree(s->d_stats); (void)hipFree(s->d_fscratch);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_tiles);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -368,9 +370,14 @@ static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
 }
 
 template <typename BT, bool STATS>
-static int launch_kernel(rt_scene *s, const KFrame &fr, hipStream_t stream) {
+static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
+  KFrame fr = fr_in;
   const int threads = 256;
+#if RT_KERNEL_VERSION >= 3
+  const size_t lds = (size_t)(threads / 64) * (fr.stack_depth + 3) * 64 * sizeof(uint2);   // + 3 rows: the pixel sums
+#else
   const size_t lds = (size_t)(threads / 64) * fr.stack_depth * 64 * sizeof(uint2);
+#endif
   if (lds > 160 * 1024) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
   auto kern = k_render_tiles<BT, STATS>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -379,6 +386,16 @@ static int launch_kernel(rt_scene *s, const KFrame &fr, hipStream_t stream) {
   per_cu = std::max(1, per_cu);
   const int want = (fr.n_tiles + 3) / 4;
   const int grid = std::max(1, std::min(want, g_ctx.n_cu * per_cu));
+#if RT_KERNEL_VERSION >= 3
+  const size_t waves = (size_t)grid * (threads / 64);
+  if (waves > s->fscratch_waves) {      // grows only on the first launch / a larger grid; never inside a steady-state loop
+    HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(s->d_fscratch); s->d_fscratch = nullptr; s->fscratch_waves = 0;
+    if (hipMalloc((void **)&s->d_fscratch, waves * PR_ROWS * 64 * sizeof(double)) != hipSuccess) return fail(RT_ERR_OOM, "clamp-bounds scratch for %zu waves", waves);
+    s->fscratch_waves = waves;
+  }
+  fr.fscratch = s->d_fscratch;
+#endif
   HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
   if (STATS) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
   KScene ks = s->ks;
