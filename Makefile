@@ -6,10 +6,11 @@
 HIPCC   ?= hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
-RT_MIN_WAVES ?= 2
+RT_MIN_WAVES ?= 3
 
 CORE_SRC := raytracer_amd/csrc/rtcore.hip
-CORE_HDR := raytracer_amd/csrc/rt_kernels.h raytracer_amd/csrc/rt_device.h include/rtcore.h
+CORE_HDR := $(wildcard raytracer_amd/csrc/*.h) include/rtcore.h
+KERNEL_DEFS ?=
 HOST_SRC := $(wildcard raytracer_amd/csrc/host/*.cpp)
 HOST_HDR := include/rthost.h include/rtcore.h
 
@@ -20,9 +21,12 @@ host: raytracer_amd/lib/librthost.so
 cli: raytracer_amd/bin/rtcli
 oracle: oracle/_build/liboracle.so
 
+# -ffp-contract=off: the reference (GHC) forms no FMAs, and hit decisions at shared edges and vertices depend on the last bit
+# of t, u and v.  With contraction off the kernel's FP64 arithmetic rounds like the reference's (measured: radiance equal to
+# ~1e-16, no primitive-id mismatches); the FP32 box tests use explicit fmaf and are not affected.
 raytracer_amd/lib/librtcore.so: $(CORE_SRC) $(CORE_HDR)
 	@mkdir -p raytracer_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(CORE_SRC) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(KERNEL_DEFS) $(CORE_SRC) -o $@
 
 # -ffp-contract=off: the BVH builder's sort keys must round exactly like the reference's doubles
 raytracer_amd/lib/librthost.so: $(HOST_SRC) $(HOST_HDR)

@@ -156,19 +156,25 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(spec, threads):
-    """The oracle (a C++ port of the reference's algorithm, oracle/oracle.cpp) timed on the host cores on
-    a bounded sample of the SAME workload: every 27th row of the frame at full spp."""
+def cpu_baseline(spec, threads, target_s=15.0):
+    """The oracle (a C++ port of the reference's algorithm, oracle/oracle.cpp) timed on the host cores on a bounded
+    sample of the SAME workload: every k-th row of the frame at full spp, k chosen from a short probe so that the
+    sample is about `target_s` seconds of CPU work.  Only the orc_render call is timed (no numpy allocation)."""
     from oracle import oracle as O
     threads = max(1, min(threads, os.cpu_count() or 1))
     o = O.OracleScene(spec)
-    stride = 27 if spec.height >= 270 else 1
-    t0 = time.perf_counter()
-    _, cnt = o.render(rows=(stride // 2, spec.height), row_stride=stride, n_threads=threads, counters=True, want_ids=False)
-    dt = time.perf_counter() - t0
+
+    def run(stride):
+        _, cnt = o.render(rows=(stride // 2, spec.height), row_stride=stride, n_threads=threads, counters=True, want_ids=False)
+        return cnt["rays_closest"] + cnt["rays_shadow"], o.last_render_s, len(range(stride // 2, spec.height, stride))
+
+    probe = max(1, spec.height // 16)                       # ~16 rows spread over the frame
+    rays, dt, rows = run(probe)
+    full_s = dt * spec.height / rows
+    stride = int(min(probe, max(1, round(full_s / target_s))))
+    if stride < probe:
+        rays, dt, rows = run(stride)
     o.close()
-    rays = cnt["rays_closest"] + cnt["rays_shadow"]
-    rows = len(range(stride // 2, spec.height, stride))
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{rows} of {spec.height} rows (every {stride}th) x {spec.width} px x {spec.spp} spp = {rays} rays in {dt:.2f} s; "
                       f"full frame extrapolates to {dt * spec.height / rows:.1f} s"}

@@ -159,6 +159,11 @@ typedef struct rt_stats {
   uint64_t nodes_visited;    /* internal nodes fetched                                     */
   uint64_t tri_tests, sphere_tests, plane_tests;
   uint64_t shaded_hits;      /* material fetches                                           */
+  /* scheduler census of the vote-scheduled kernel: wave-level trips through each body */
+  uint64_t sched_node_steps, sched_prim_steps, sched_shade_steps;
+  uint64_t top_node_hits;      /* node visits served by the LDS copy of the top BVH levels */
+  uint64_t sched_live_lanes;   /* sum over all trips of the lanes that still had work */
+  uint64_t cyc_vote, cyc_node, cyc_prim, cyc_shade, cyc_refill;   /* shader-clock ticks summed over waves, per body */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -6,6 +6,7 @@ classes of the public ABI), no product compute code.
 """
 from __future__ import annotations
 
+import time
 import ctypes as C
 import os
 
@@ -134,9 +135,11 @@ class OracleScene:
         rgb = np.zeros((H, W, 3), np.uint8); ids = np.full((H, W), -2, np.int32)
         cnt = orc_counters()
         cam = camera if camera is not None else self.camera
+        t0 = time.perf_counter()
         rc = lib().orc_render(self._h, C.byref(cam), C.byref(p), r0, r1, row_stride, n_threads, _dp(rad), _dp(col),
                               rgb.ctypes.data_as(F.c_uint8_p), _ip(ids) if want_ids else None,
                               C.byref(cnt) if counters else None)
+        self.last_render_s = time.perf_counter() - t0      # the orc_render call alone (bench.py cpu_baseline)
         if rc != 0:
             raise ValueError(f"orc_render failed: {rc}")
         res = {"radiance": rad, "color": col, "rgb8": rgb, "prim_id": ids}

@@ -63,7 +63,10 @@ class rt_stats(C.Structure):
     _fields_ = [("ms_render", C.c_double), ("ms_total", C.c_double), ("paths", C.c_uint64),
                 ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("plane_tests", C.c_uint64),
-                ("shaded_hits", C.c_uint64)]
+                ("shaded_hits", C.c_uint64),
+                ("sched_node_steps", C.c_uint64), ("sched_prim_steps", C.c_uint64), ("sched_shade_steps", C.c_uint64),
+                ("top_node_hits", C.c_uint64), ("sched_live_lanes", C.c_uint64),
+                ("cyc_vote", C.c_uint64), ("cyc_node", C.c_uint64), ("cyc_prim", C.c_uint64), ("cyc_shade", C.c_uint64), ("cyc_refill", C.c_uint64)]
 
 
 class rth_config_view(C.Structure):

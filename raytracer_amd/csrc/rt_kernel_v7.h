@@ -1,0 +1,488 @@
+// rt_kernel_v7.h — the render kernel as a VOTE-SCHEDULED per-lane state machine, cold path state out of
+// the register file (v3), and LANES AS WORKERS that pull pixels from a pool (v4).
+//
+// v1 ran one complete BVH query per lane per outer trip, so every lane waited for the longest
+// traversal of its wave (measured VALU lane utilisation 22 %, profiles/r01_summary.md).  Since v2
+// every lane carries its traversal state across trips and each trip of the wave executes exactly ONE
+// of three bodies, picked by wave-uniform ballots:
+//     NODE  step : lanes at an internal node fetch it, test both child boxes, descend / push / pop
+//     PRIM  step : lanes in a leaf test one primitive and advance / pop
+//     SHADE step : lanes whose query finished run the path state transition (light loop, material
+//                  bounce, path end, next sample) and start their next query
+// so a finished lane never idles until the slowest ray of the wave is done.
+//
+// v3: only the TRAVERSAL state (ray, closest hit, stack pointer, box-space ray: ~40 registers) is live
+// during NODE/PRIM steps.  The path state that only SHADE needs — incoming direction, normal,
+// attenuation, the pending clamp function F(x) = clamp(x + a, L, H), sample/bounce counters — is a
+// per-lane RECORD in a global scratch row ([wave][row][lane], coalesced 512-B rows, L2-resident); SHADE
+// loads the fields it needs and stores the ones it changes.  The pixel's running sum lives in LDS.
+// That takes the kernel from 256 VGPRs (2 waves/SIMD) towards 4 waves/SIMD.
+// Numerics: emission and each light's term are added to `a` as they arrive, i.e. the reference's
+// `e + surf*(l1 + (l2 + ...)) + clamp(..)` is summed in a different order (~1e-16 relative).
+//
+// v4: in v3 a wave owned one 8x8 tile until its slowest pixel was done; on the metric scene only 48 of 64
+// lanes still had work on an average trip.  Now a lane that finishes its pixel (all spp samples, summed in
+// order) writes it out and immediately takes the next pixel slot from a wave-local pool, which the wave
+// refills one tile (64 slots, tile order) at a time from the global atomic counter.  A wave therefore stays
+// full until the frame runs dry; pixels of at most a few consecutive tiles share a wave (coherence kept).
+// Results are unchanged: a pixel is still computed by ONE lane, sample by sample, RNG keyed by the pixel.
+//
+// v5: LDS-cached top of the BVH.  rocprofv3 shows v3/v4 bound by the vector L1 (TCP active 88 %, TD busy 77 %,
+// ~113 scattered cache-line accesses per ray, profiles/): every lane's node fetch is 4 x 16 B from its own line.
+// The internal nodes are stored top levels first (breadth-first), so the first `top_nodes` of them — the ones
+// every ray walks through — are copied into LDS once per workgroup; ONE workgroup of RT_BLOCK_THREADS threads
+// per CU shares that copy, and a NODE step reads cached nodes with ds_read_b128 instead of going through the TCP.
+//
+// v6: the lane state lives in ONE register: cur >= 0 internal node, CUR_IDLE no pixel, CUR_DONE query finished
+// (waiting for SHADE), anything else negative = leaf reference; cached nodes are read with explicit LDS loads
+// (v5's pointer select made the compiler emit FLAT loads, which still occupy the vector-memory path), global
+// nodes/primitives are addressed with 32-bit offsets from a scalar base, and the NODE body is branch-light.
+//
+// v7: the occupancy sweep shows the SIMDs instruction-issue bound, with ~45 % of the
+// issued instructions being SALU/branch overhead of divergent control flow.  The NODE and PRIM bodies are
+// therefore STRAIGHT-LINE predicated code: selects instead of nested ifs, no early exits in the triangle test,
+// two inline predicated pops (a lane whose two popped entries were both culled continues in state CUR_POP),
+// spheres/planes behind a wave-uniform branch that all-triangle leaves never take.
+#pragma once
+#define CUR_IDLE ((int)0x80000000)
+#define CUR_DONE ((int)0x80000001)
+#define CUR_POP  ((int)0x80000002)   // keeps popping at the next NODE trip
+#ifndef RT_NODE_UNROLL
+#define RT_NODE_UNROLL 4    // node visits per NODE trip (amortises the vote; measured 1: 290 ms, 2: 280, 3: 269, 4: 266 on C4)
+#endif
+#ifdef RT_ASM_MARKERS
+#define RT_MARK(name) asm volatile("; RTMARK " name ::: "memory")
+#else
+#define RT_MARK(name) do { } while (0)
+#endif
+#ifndef RT_BLOCK_THREADS
+#define RT_BLOCK_THREADS 768
+#endif
+
+#ifndef RT_NODE_WEIGHT
+#define RT_NODE_WEIGHT 1    // NODE step runs while n_node * WEIGHT >= n_leaf
+#endif
+#ifndef RT_SHADE_NUM
+#define RT_SHADE_NUM 1      // run the SHADE body once >= NUM/DEN of the wave's live lanes wait for it
+#endif
+#ifndef RT_SHADE_DEN
+#define RT_SHADE_DEN 2
+#endif
+
+// rows of the per-lane path record (doubles; 64 lanes per row)
+#ifndef RT_REC_ROWS_DEFINED
+#define RT_REC_ROWS_DEFINED
+enum { PR_UDIR = 0, PR_NRM = 3, PR_ATT = 6, PR_FA = 9, PR_FL = 12, PR_FH = 15, PR_SB = 18 /* int2: sample, bounce */,
+       PR_MF = 19 /* int2: material index, front face */, PR_ROWS = 20 };
+
+RT_DEV d3 rec_ld(const double *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
+RT_DEV void rec_st(double *r, int row, d3 v) { r[row * 64] = v.x; r[(row + 1) * 64] = v.y; r[(row + 2) * 64] = v.z; }
+RT_DEV int2 rec_ldi(const double *r, int row) { return *(const int2 *)(r + row * 64); }
+RT_DEV void rec_sti(double *r, int row, int a, int b) { *(int2 *)(r + row * 64) = make_int2(a, b); }
+#endif
+
+
+// gamma correction c ** gamma (Trace.hs:103-105), out of line: the FP64 pow body must not set the kernel's register budget
+__device__ __attribute__((noinline)) double pow_gamma(double c, double g) { return pow(c, g); }
+
+template <typename BT, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
+  extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: [entry][lane] stack + [3][lane] pixel sums
+  const int lane = threadIdx.x & 63;
+  const float4 *lnodes = (const float4 *)lds_all;          // 4 x float4 per cached FP32 node
+  uint2 *stack = lds_all + (size_t)fr.top_nodes * 8 + (size_t)(threadIdx.x >> 6) * (fr.stack_depth + 3) * 64 + lane;
+  double *lsum = (double *)(stack + (size_t)fr.stack_depth * 64);       // lsum[k*64], k = 0..2
+  double *rec = fr.fscratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PR_ROWS * 64 + lane;
+  const DNode<BT> *nodes = (const DNode<BT> *)sc.nodes;
+  const double inf = __builtin_huge_val();
+  const BT tminb = tmin_for_boxes<BT>();
+
+  uint32_t st[STAT_COUNT];
+#pragma unroll
+  for (int i = 0; i < STAT_COUNT; ++i) st[i] = 0;
+
+  if (fr.top_nodes > 0) {                                  // fill the node cache: coalesced 16-B copies, once per workgroup
+    const float4 *src = (const float4 *)sc.nodes;
+    float4 *dst = (float4 *)lds_all;
+    for (int i = threadIdx.x; i < fr.top_nodes * 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  // ---- per-lane pixel (the lane's current work item) and traversal state (registers)
+  uint32_t pixel = 0;                                      // row*W + col, also the RNG key
+  uint32_t slot = 0;                                       // where this pixel's outputs go
+  d3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+  BoxRay<BT> br;
+  BT tmaxb = (BT)0;
+  double best_t = 0.0;
+  int best = -1, cur = CUR_IDLE, sp = 0, li = -1;          // li >= 0: the query is the shadow ray of light li
+  // ---- wave-uniform pool of pixel slots [pool_next, pool_end) in tile order
+  uint32_t pool_next = 0, pool_end = 0;
+  bool exhausted = false;
+
+#define RT_BEGIN_QUERY(q_tmax)                                                     \
+  do {                                                                             \
+    make_boxray(br, ro, rd, sc.rscene);                                            \
+    best_t = (q_tmax); tmaxb = tmax_for_boxes<BT>(best_t);                         \
+    best = -1; sp = 0; cur = sc.root_ref;                                          \
+    if (STATS) st[li >= 0 ? STAT_SHADOW : STAT_CLOSEST]++;                         \
+  } while (0)
+#define RT_POP()                                                                   \
+  do {                                                                             \
+    for (;;) {                                                                     \
+      if (sp == 0) { cur = CUR_DONE; break; }                                      \
+      --sp;                                                                        \
+      const uint2 e_ = stack[sp * 64];                                             \
+      if (!cull_entry(__uint_as_float(e_.y), tmaxb)) { cur = (int)e_.x; break; }   \
+    }                                                                              \
+  } while (0)
+// Branch-free pop for the lanes with p_ set: up to two entries; entries beyond the closest hit are skipped.
+#define RT_POP2(p_)                                                                  \
+  do {                                                                               \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) {                               \
+      const int spn_ = sp - 1;                                                       \
+      const uint2 e_ = stack[(spn_ < 0 ? 0 : spn_) * 64];                            \
+      const bool empty_ = sp == 0;                                                   \
+      const bool culled_ = cull_entry(__uint_as_float(e_.y), tmaxb);                 \
+      cur = (p_) ? (empty_ ? CUR_DONE : (culled_ ? cur : (int)e_.x)) : cur;          \
+      sp = ((p_) && !empty_) ? spn_ : sp;                                            \
+      p_ = (p_) && !empty_ && culled_;                                               \
+    }                                                                                \
+    cur = (p_) ? CUR_POP : cur;                                                      \
+  } while (0)
+#define RT_WRITE_PIXEL()                                                                                                   \
+  do {                                                                                                                     \
+    const d3 avg_ = (1.0 / (double)fr.spp) * mk3(lsum[0], lsum[64], lsum[128]);       /* RenderWorker.hs:114 */            \
+    const double e_x = fr.exposure;                                                                                        \
+    const d3 toned_ = mk3(avg_.x * e_x / (avg_.x * e_x + 1), avg_.y * e_x / (avg_.y * e_x + 1), avg_.z * e_x / (avg_.z * e_x + 1)); /* Trace.hs:96-101 */ \
+    const size_t o_ = 3 * (size_t)slot;                                                                                    \
+    if (fr.out_radiance) { fr.out_radiance[o_] = avg_.x; fr.out_radiance[o_ + 1] = avg_.y; fr.out_radiance[o_ + 2] = avg_.z; } \
+    if (fr.out_color) {                                                                                                    \
+      const double tc_[3] = {toned_.x, toned_.y, toned_.z};                                                                \
+      _Pragma("nounroll") for (int c_ = 0; c_ < 3; ++c_) fr.out_color[o_ + c_] = pow_gamma(tc_[c_], fr.gamma);             \
+    }                                                                                                                      \
+  } while (0)
+
+  // Gives every idle lane its next pixel slot.  All lanes of the wave run this (uniform control flow).
+  auto refill = [&]() {
+    for (;;) {
+      const unsigned long long need = __ballot(cur == CUR_IDLE);
+      if (need == 0ull) break;
+      if (pool_next == pool_end) {                         // pool empty: take the next tile from the global counter
+        uint32_t ti = 0;
+        if (lane == 0) ti = atomicAdd(fr.tile_counter, 1u);
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        if (ti >= (uint32_t)fr.n_tiles) { exhausted = true; break; }
+        pool_next = ti * 64u; pool_end = pool_next + 64u;
+      }
+      const uint32_t avail = pool_end - pool_next;
+      const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));   // my index among the idle lanes
+      const uint32_t n_need = (uint32_t)__popcll(need);
+      if (cur == CUR_IDLE && rank < avail) {
+        const uint32_t q = pool_next + rank;               // pixel slot q = local tile * 64 + position in the 8x8 tile
+        const uint32_t lt = q >> 6, pos = q & 63u;
+        const int tile = fr.tiles ? fr.tiles[lt] : (int)lt;
+        const int px = (tile % fr.tiles_x) * 8 + (int)(pos & 7u);
+        const int py = (tile / fr.tiles_x) * 8 + (int)(pos >> 3);
+        if (px < fr.W && py < fr.H) {                      // slots outside the image are consumed and dropped
+          pixel = (uint32_t)(py * fr.W + px);
+          slot = fr.packed ? q : pixel;
+          lsum[0] = 0.0; lsum[64] = 0.0; lsum[128] = 0.0;
+          if (fr.out_primid) fr.out_primid[slot] = -1;
+          if (fr.maxb > 0) {
+            camera_ray(fr, px, py, pixel, 0u, ro, rd);
+            rec_st(rec, PR_ATT, mk3(1, 1, 1)); rec_st(rec, PR_FA, mk3(0, 0, 0));
+            rec_st(rec, PR_FL, mk3(-inf, -inf, -inf)); rec_st(rec, PR_FH, mk3(inf, inf, inf));
+            rec_sti(rec, PR_SB, 0, 0);
+            li = -1;
+            RT_BEGIN_QUERY(RT_TMAX);
+          } else {
+            // traceLoop _ 0: every sample is the background along its camera ray (Trace.hs:22); nothing is traced
+            for (int s = 0; s < fr.spp; ++s) {
+              d3 o_, d_;
+              camera_ray(fr, px, py, pixel, (uint32_t)s, o_, d_);
+              const d3 b_ = background(sc, d_);
+              lsum[0] += b_.x; lsum[64] += b_.y; lsum[128] += b_.z;
+            }
+            RT_WRITE_PIXEL();
+          }
+        }
+      }
+      pool_next += n_need < avail ? n_need : avail;
+    }
+  };
+
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = STATS ? clock64() : 0ull;   // vote, node, prim, shade, refill
+#define RT_TICK(k) do { if (STATS) { const unsigned long long n_ = clock64(); tacc[k] += n_ - tlast; tlast = n_; } } while (0)
+  refill();
+  RT_TICK(4);
+  for (;;) {
+    const bool at_node = cur >= 0 || cur == CUR_POP;
+    const bool at_leaf = (uint32_t)cur > (uint32_t)CUR_POP;
+    const int n_node = __popcll(__ballot(at_node));
+    const int n_leaf = __popcll(__ballot(at_leaf));
+    const int n_done = __popcll(__ballot(cur == CUR_DONE));
+    const int n_act = n_node + n_leaf + n_done;
+    if (n_act == 0) break;                                 // nothing in flight and the refill found nothing: frame done
+    if (STATS && lane == 0) st[STAT_LIVE] += (uint32_t)n_act;
+
+    if (n_done * RT_SHADE_DEN >= n_act * RT_SHADE_NUM || n_node + n_leaf == 0) {
+      // ================================================= SHADE step: lanes whose query finished
+      if (STATS) st[STAT_IT_SHADE]++;
+      RT_TICK(0);
+      RT_MARK("SHADE_BEGIN");
+      if (cur == CUR_DONE) {
+        double *r = rec;
+        asm volatile("" : "+v"(r) : : "memory");            // the record is re-read from memory, never carried in registers
+        const bool anyhit = li >= 0;
+        bool need_scatter = false, need_finish = false;
+        double q_tmax = RT_TMAX;
+        bool need_ray0 = false;                              // background along the PRIMARY ray (depth exhausted, Trace.hs:22)
+        d3 bgdir = rd;
+        if (!anyhit) {
+          if (best < 0) {                                    // Trace.hs:25: background along the current ray
+            need_finish = true;
+          } else {
+            const int2 sb = rec_ldi(r, PR_SB);
+            if (sb.x == 0 && sb.y == 0 && fr.out_primid) fr.out_primid[slot] = sc.prim_ids[best];
+            const DPrim P = sc.prims[best];
+            const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+            const d3 hp = ro + best_t * rd;                  // R.at ray t
+            d3 outward;
+            if (kind == RT_PRIM_TRIANGLE) outward = normalize3(cross3(mk3(P.d[3], P.d[4], P.d[5]), mk3(P.d[6], P.d[7], P.d[8])));   // Triangle.hs:51
+            else if (kind == RT_PRIM_SPHERE) outward = (1.0 / P.d[3]) * (hp - mk3(P.d[0], P.d[1], P.d[2]));                        // Sphere.hs:38
+            else outward = mk3(P.d[3], P.d[4], P.d[5]);                                                                            // Plane.hs:29
+            const bool front = dot3(rd, outward) < 0;        // Class.hs:24
+            rec_st(r, PR_NRM, front ? outward : neg3(outward));   // :25
+            rec_st(r, PR_UDIR, normalize3(rd));              // Trace.hs:32
+            rec_sti(r, PR_MF, P.mat, front ? 1 : 0);
+            rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(sc.mats[P.mat].emission));   // emitted (Trace.hs:29) joins the pending offset
+            ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
+            if (STATS) st[STAT_SHADED]++;
+            if (sc.n_lights > 0) li = sc.n_lights - 1; else need_scatter = true;
+          }
+        } else {
+          if (best < 0) {                                    // unblocked: Light.hs:36-38 / :48-49
+            const DLight L = sc.lights[li];
+            const d3 lnormal = normalize3(rec_ld(r, PR_NRM));   // Light.hs:19
+            const double lightPower = fmax(0.0, dot3(lnormal, rd));
+            d3 contrib;
+            if (L.kind == RT_LIGHT_POINT) {
+              const d3 tl = ld3(L.vec) - ro;
+              const double dist = sqrt(dot3(tl, tl));
+              const double attenuation = 1 / (dist * dist);
+              contrib = (lightPower * attenuation) * ld3(L.intensity);
+            } else {
+              contrib = lightPower * ld3(L.intensity);
+            }
+            const int mi = rec_ldi(r, PR_MF).x;              // litColor = surfaceColor * directLight (Trace.hs:36), light by light
+            rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(sc.mats[mi].diffuse) * contrib);
+          }
+          --li;
+          if (li < 0) need_scatter = true;
+        }
+        if (!need_scatter && !need_finish) {                 // shadow ray towards light li (Light.hs:26-30, 39-42)
+          const DLight L = sc.lights[li];
+          if (L.kind == RT_LIGHT_POINT) {
+            const d3 tl = ld3(L.vec) - ro;
+            rd = normalize3(tl);
+            q_tmax = sqrt(dot3(tl, tl)) - 0.01;
+          } else {
+            rd = normalize3(-1.0 * ld3(L.vec));
+            q_tmax = RT_TMAX;
+          }
+        }
+        if (need_scatter) {                                  // Trace.hs:27-76
+          const int2 mf = rec_ldi(r, PR_MF);
+          const int2 sb = rec_ldi(r, PR_SB);
+          const DMaterial M = sc.mats[mf.x];
+          const bool front = mf.y != 0;
+          const d3 udir = rec_ld(r, PR_UDIR), nrm = rec_ld(r, PR_NRM);
+          // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
+          //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)
+          {
+            const d3 Fa = rec_ld(r, PR_FA), FL = rec_ld(r, PR_FL), FH = rec_ld(r, PR_FH);
+            rec_st(r, PR_FL, clamp3(Fa, FL, FH));
+            rec_st(r, PR_FH, clamp3(mk3(Fa.x + 10.0, Fa.y + 10.0, Fa.z + 10.0), FL, FH));
+          }
+          const u4 w = philox4x32_10(pixel, (uint32_t)sb.x, 1u + (uint32_t)sb.y, 0u, fr.key0, fr.key1);
+          const d3 randVec = normalize3(mk3(um11(w.x), um11(w.y), um11(w.z)));   // :38-42
+          const double randD = u01(w.w);                                         // :41
+          if (M.flags & DMAT_GLASS_DIR) {                                        // :48-59
+            const double eta = front ? 1.0 / M.ior : M.ior;
+            const double cosTheta = fmin(-dot3(udir, nrm), 1.0);
+            const double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
+            const double r0 = (1 - eta) / (1 + eta);                             // schlick, :85-89
+            const double r0sq = r0 * r0;
+#ifdef RT_SCHLICK_POW
+            const double reflectProb = r0sq + (1 - r0sq) * pow(1 - cosTheta, 5.0);
+#else
+            const double omc = 1 - cosTheta;                                     // (1-cos)**5 by multiplication: <= 1 ulp from pow()
+            const double reflectProb = r0sq + (1 - r0sq) * (omc * omc * omc * omc * omc);
+#endif
+            if (eta * sinTheta > 1.0 || randD < reflectProb) rd = reflect3(udir, nrm);
+            else rd = refract3(udir, nrm, eta);
+          } else if (M.flags & DMAT_METAL) {                                     // :60-64
+            rd = normalize3(reflect3(udir, nrm) + 0.05 * randVec);
+          } else {                                                               // :65-67
+            rd = normalize3(nrm + randVec);
+          }
+          d3 atten = rec_ld(r, PR_ATT);
+          if (!(M.flags & DMAT_NO_ATTEN)) { atten = atten * ld3(M.diffuse); rec_st(r, PR_ATT, atten); }   // :69-72
+          rec_sti(r, PR_SB, sb.x, sb.y + 1);
+          li = -1;
+          if (sb.y + 1 >= fr.maxb) { need_ray0 = true; need_finish = true; }     // depth 0: background along ray0, :22
+        }
+        if (need_finish) {
+          // ONE camera_ray and ONE background call site (their libm-heavy bodies are inlined once): pass 0 regenerates
+          // the primary ray of this sample when the depth ran out, pass 1 starts the next sample's path.
+          const int s_cur = rec_ldi(r, PR_SB).x;
+#pragma nounroll
+          for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 0 ? need_ray0 : (s_cur + 1 < fr.spp)) {
+              d3 o_, d_;
+              camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)(s_cur + pass), o_, d_);
+              if (pass == 0) bgdir = d_; else { ro = o_; rd = d_; }
+            }
+            if (pass == 0) {
+              const d3 T = rec_ld(r, PR_ATT) * background(sc, bgdir);
+              const d3 R = clamp3(T + rec_ld(r, PR_FA), rec_ld(r, PR_FL), rec_ld(r, PR_FH));
+              lsum[0] += R.x; lsum[64] += R.y; lsum[128] += R.z;
+            }
+          }
+          if (s_cur + 1 < fr.spp) {
+            rec_st(r, PR_ATT, mk3(1, 1, 1)); rec_st(r, PR_FA, mk3(0, 0, 0));
+            rec_st(r, PR_FL, mk3(-inf, -inf, -inf)); rec_st(r, PR_FH, mk3(inf, inf, inf));
+            rec_sti(r, PR_SB, s_cur + 1, 0);
+            li = -1; q_tmax = RT_TMAX;
+          } else {
+            RT_WRITE_PIXEL();                                // last sample of this pixel: tone map, gamma, store
+            cur = CUR_IDLE;                                  // the lane is free: it pulls its next pixel in the refill below
+          }
+        }
+        if (cur != CUR_IDLE) RT_BEGIN_QUERY(q_tmax);
+      }
+      RT_MARK("SHADE_END");
+      RT_TICK(3);
+      if (!exhausted) refill();
+      RT_TICK(4);
+      RT_MARK("REFILL_END");
+    } else if (n_node * RT_NODE_WEIGHT >= n_leaf) {
+      // ================================================= NODE step (BVH.hs:123-143)
+      if (STATS) st[STAT_IT_NODE]++;
+      RT_TICK(0);
+      RT_MARK("NODE_BEGIN");
+#pragma unroll
+      for (int it = 0; it < RT_NODE_UNROLL; ++it) {
+        const bool isn = cur >= 0;
+        bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
+        if (STATS && isn) st[STAT_NODES]++;
+        bool hL, hR;
+        BT tL, tR;
+        int refL = 0, refR = 0;
+        if constexpr (sizeof(BT) == 4) {
+          float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+          int2 q3 = make_int2(0, 0);
+          if (isn) {
+            if (cur < fr.top_nodes) {                        // top of the tree: the workgroup's LDS copy (ds_read_b128)
+              const float4 *p = lnodes + 4 * cur;
+              q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
+              asm volatile("" ::: "memory");                 // keep this an LDS load: do not merge with the global path into a FLAT load
+              if (STATS) st[STAT_TOPHIT]++;
+            } else {                                         // scalar base + 32-bit lane offset
+              const char *p = (const char *)nodes + (size_t)((uint32_t)cur << 6);
+              q0 = *(const float4 *)p; q1 = *(const float4 *)(p + 16); q2 = *(const float4 *)(p + 32); q3 = *(const int2 *)(p + 48);
+            }
+          }
+          const float bxL[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+          const float bxR[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+          hL = box_test(br, bxL, tminb, tmaxb, tL) && isn;
+          hR = box_test(br, bxR, tminb, tmaxb, tR) && isn;
+          refL = q3.x; refR = q3.y;
+        } else {
+          DNode<BT> nd;
+          for (int k = 0; k < 12; ++k) nd.box[k] = 0;
+          if (isn) nd = nodes[cur];
+          hL = box_test(br, nd.box, tminb, tmaxb, tL) && isn;
+          hR = box_test(br, nd.box + 6, tminb, tmaxb, tR) && isn;
+          refL = nd.ref[0]; refR = nd.ref[1];
+        }
+        const bool lf = tL < tR;                             // BVH.hs:132: nearer child first, tie => right first
+        if (hL && hR) {                                      // push the farther child with its entry distance
+          const BT ts = lf ? tR : tL;
+          float tsf;
+          if constexpr (sizeof(BT) == 8) tsf = __double2float_rd((double)ts); else tsf = (float)ts;
+          stack[sp * 64] = make_uint2((uint32_t)(lf ? refR : refL), __float_as_uint(tsf));
+          ++sp;
+        }
+        cur = (hL || hR) ? ((hL && (lf || !hR)) ? refL : refR) : cur;
+        pp = pp || (isn && !(hL || hR));
+        RT_POP2(pp);
+      }
+      RT_TICK(1);
+    } else {
+      // ================================================= PRIM step (closestHitList, HitHelpers.hs:11-16)
+      RT_MARK("NODE_END");
+      if (STATS) st[STAT_IT_PRIM]++;
+      RT_TICK(0);
+      RT_MARK("PRIM_BEGIN");
+      {
+        const bool isl = at_leaf;
+        const int pi = ~cur;
+        DPrim P;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) P.d[k] = 0.0;
+        P.mat = 0; P.kind = 0;
+        if (isl) P = *(const DPrim *)((const char *)sc.prims + (size_t)((uint32_t)pi * 80u));
+        const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+        // Moller-Trumbore without early exits (Triangle.hs:30-53): same operations, same order, the rejections become one predicate
+        double t;
+        bool h;
+        {
+          const d3 p0 = mk3(P.d[0], P.d[1], P.d[2]), e1 = mk3(P.d[3], P.d[4], P.d[5]), e2 = mk3(P.d[6], P.d[7], P.d[8]);
+          const d3 hh = cross3(rd, e2);                      // :34
+          const double a = dot3(e1, hh);                     // :35
+          const double f = 1.0 / a;                          // :39
+          const d3 sv = ro - p0;                             // :40
+          const double u = f * dot3(sv, hh);                 // :41
+          const d3 q = cross3(sv, e1);                       // :45
+          const double v = f * dot3(rd, q);                  // :46
+          t = f * dot3(e2, q);                               // :50
+          h = !(fabs(a) < 1e-8) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && (t >= RT_TMIN && t <= best_t);   // :36,42,47,53
+        }
+        if (STATS && isl && kind == RT_PRIM_TRIANGLE) st[STAT_TRI]++;
+        if (__ballot(isl && kind != RT_PRIM_TRIANGLE) != 0ull) {   // wave-uniform: leaves with spheres/planes are rare
+          if (isl && kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro, rd, RT_TMIN, best_t, t); }
+#ifndef RT_X_NO_PLANE
+          else if (isl && kind == RT_PRIM_PLANE) { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro, rd, RT_TMIN, best_t, t); }
+#endif
+        }
+        h = h && isl;
+        best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
+        best = h ? pi : best;
+        tmaxb = h ? tmax_for_boxes<BT>(t) : tmaxb;
+        const bool blocked = h && li >= 0;                   // shadow ray: any hit blocks (Light.hs:30-32)
+        const bool last = (P.kind & DPRIM_LAST) != 0u;
+        cur = isl ? (blocked ? CUR_DONE : (last ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)
+        bool pp = isl && !blocked && last;
+        RT_POP2(pp);
+      }
+      RT_TICK(2);
+    }
+  }
+#undef RT_BEGIN_QUERY
+#undef RT_POP
+#undef RT_POP2
+#undef RT_WRITE_PIXEL
+
+  if (STATS && lane == 0) {
+    for (int k = 0; k < 5; ++k) atomicAdd(fr.stats + STAT_T_VOTE + k, tacc[k]);
+  }
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < STAT_T_VOTE; ++i) {
+      unsigned long long v = wave_sum((unsigned long long)st[i]);
+      if (lane == 0 && v) atomicAdd(fr.stats + i, v);
+    }
+  }
+}

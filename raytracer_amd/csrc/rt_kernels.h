@@ -49,9 +49,10 @@ struct KFrame {
   unsigned long long *stats;   // 8 counters, see STAT_*
   double *fscratch;            // v3: [grid waves][6][64] doubles, the per-lane bounds of the pending clamp function
   int32_t stack_depth;
+  int32_t top_nodes;           // v5: the first top_nodes internal nodes (top levels, breadth-first) are cached in LDS
 };
 
-enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_COUNT };
+enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
 
 // cold code (once per path, not per traversal step) is kept out of line so that its temporaries do not
 // inflate the register allocation of the hot step bodies
@@ -259,17 +260,15 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 
 // ---------------------------------------------------------------- the render kernel
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 2
+#define RT_MIN_WAVES 3
 #endif
 #ifndef RT_KERNEL_VERSION
-#define RT_KERNEL_VERSION 3
+#define RT_KERNEL_VERSION 7
 #endif
 #if RT_KERNEL_VERSION == 1
-#include "rt_kernel_v1.h"
-#elif RT_KERNEL_VERSION == 2
-#include "rt_kernel_v2.h"
+#include "rt_kernel_v1.h"     // baseline kept for A/B runs: every lane runs whole queries, no vote scheduling (344 ms on C4)
 #else
-#include "rt_kernel_v3.h"
+#include "rt_kernel_v7.h"     // the product kernel: vote-scheduled NODE / PRIM / SHADE bodies (266 ms on C4)
 #endif
 
 // ---------------------------------------------------------------- small helper kernels

@@ -13,6 +13,9 @@
 #include <string>
 #include <vector>
 
+#ifndef RT_TOP_NODES_MAX
+#define RT_TOP_NODES_MAX 1023
+#endif
 #include "rt_kernels.h"
 
 namespace {
@@ -372,9 +375,24 @@ static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
 template <typename BT, bool STATS>
 static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   KFrame fr = fr_in;
+#if RT_KERNEL_VERSION != 1
+  const int threads = RT_BLOCK_THREADS;
+#else
   const int threads = 256;
-#if RT_KERNEL_VERSION >= 3
-  const size_t lds = (size_t)(threads / 64) * (fr.stack_depth + 3) * 64 * sizeof(uint2);   // + 3 rows: the pixel sums
+#endif
+#if RT_KERNEL_VERSION != 1
+  // LDS: per wave the stack and 3 rows of pixel sums; what is left of 160 KB (one workgroup per CU) caches top BVH levels
+  const size_t lds_waves = (size_t)(threads / 64) * (fr.stack_depth + 3) * 64 * sizeof(uint2);
+  fr.top_nodes = 0;
+  if (sizeof(BT) == 4 && lds_waves < 156 * 1024) {
+    size_t room = (156 * 1024 - lds_waves) / sizeof(DNode<float>);
+    int cap = RT_TOP_NODES_MAX;
+    const char *env = getenv("RT_TOP_NODES");               // experiment knob
+    if (env) cap = atoi(env);
+    fr.top_nodes = (int)std::min<size_t>(std::min<size_t>(room, (size_t)cap), (size_t)s->n_internal);
+  }
+  size_t lds = lds_waves + (size_t)fr.top_nodes * sizeof(DNode<float>);
+  if (const char *pad = getenv("RT_LDS_BYTES")) lds = std::max(lds, (size_t)atol(pad));   // experiment knob: caps blocks per CU
 #else
   const size_t lds = (size_t)(threads / 64) * fr.stack_depth * 64 * sizeof(uint2);
 #endif
@@ -384,9 +402,9 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
   per_cu = std::max(1, per_cu);
-  const int want = (fr.n_tiles + 3) / 4;
+  const int want = (fr.n_tiles + threads / 64 - 1) / (threads / 64);
   const int grid = std::max(1, std::min(want, g_ctx.n_cu * per_cu));
-#if RT_KERNEL_VERSION >= 3
+#if RT_KERNEL_VERSION != 1
   const size_t waves = (size_t)grid * (threads / 64);
   if (waves > s->fscratch_waves) {      // grows only on the first launch / a larger grid; never inside a steady-state loop
     HIP_TRY(hipStreamSynchronize(stream));
@@ -438,6 +456,10 @@ static int read_stats(rt_scene *s, rt_stats *st) {
   HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
   st->rays_closest = h[STAT_CLOSEST]; st->rays_shadow = h[STAT_SHADOW]; st->nodes_visited = h[STAT_NODES];
   st->tri_tests = h[STAT_TRI]; st->sphere_tests = h[STAT_SPHERE]; st->plane_tests = h[STAT_PLANE]; st->shaded_hits = h[STAT_SHADED];
+  st->sched_node_steps = h[STAT_IT_NODE] / 64; st->sched_prim_steps = h[STAT_IT_PRIM] / 64; st->sched_shade_steps = h[STAT_IT_SHADE] / 64;
+  st->sched_live_lanes = h[STAT_LIVE];
+  st->top_node_hits = h[STAT_TOPHIT];
+  st->cyc_vote = h[STAT_T_VOTE]; st->cyc_node = h[STAT_T_NODE]; st->cyc_prim = h[STAT_T_PRIM]; st->cyc_shade = h[STAT_T_SHADE]; st->cyc_refill = h[STAT_T_REFILL];
   return RT_OK;
 }
 
