@@ -47,6 +47,9 @@
 #define CUR_IDLE ((int)0x80000000)
 #define CUR_DONE ((int)0x80000001)
 #define CUR_POP  ((int)0x80000002)   // keeps popping at the next NODE trip
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 1      // 1: a lane that reaches a leaf postpones it and keeps traversing until it holds a second one
+#endif
 #ifndef RT_NODE_UNROLL
 #define RT_NODE_UNROLL 4    // node visits per NODE trip (amortises the vote; measured 1: 290 ms, 2: 280, 3: 269, 4: 266 on C4)
 #endif
@@ -61,6 +64,9 @@
 
 #ifndef RT_NODE_WEIGHT
 #define RT_NODE_WEIGHT 1    // NODE step runs while n_node * WEIGHT >= n_leaf
+#endif
+#ifndef RT_LEAF_WEIGHT
+#define RT_LEAF_WEIGHT 1
 #endif
 #ifndef RT_SHADE_NUM
 #define RT_SHADE_NUM 1      // run the SHADE body once >= NUM/DEN of the wave's live lanes wait for it
@@ -116,6 +122,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   BT tmaxb = (BT)0;
   double best_t = 0.0;
   int best = -1, cur = CUR_IDLE, sp = 0, li = -1;          // li >= 0: the query is the shadow ray of light li
+  // Speculative traversal (FP32 boxes only; the FP64 parity mode visits exactly the reference's nodes): `pend` is a
+  // postponed leaf (0 = none).  Leaves are still tested in traversal order (pend before cur), so ties resolve as in
+  // the reference; nodes visited before the postponed leaf has narrowed the interval are a superset of the reference's.
+  constexpr bool SPEC = (RT_SPECULATE != 0) && sizeof(BT) == 4;
+  int pend = 0;
   // ---- wave-uniform pool of pixel slots [pool_next, pool_end) in tile order
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   do {                                                                             \
     make_boxray(br, ro, rd, sc.rscene);                                            \
     best_t = (q_tmax); tmaxb = tmax_for_boxes<BT>(best_t);                         \
-    best = -1; sp = 0; cur = sc.root_ref;                                          \
+    best = -1; sp = 0; cur = sc.root_ref; pend = 0;                                \
     if (STATS) st[li >= 0 ? STAT_SHADOW : STAT_CLOSEST]++;                         \
   } while (0)
 #define RT_POP()                                                                   \
@@ -217,12 +228,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   refill();
   RT_TICK(4);
   for (;;) {
-    const bool at_node = cur >= 0 || cur == CUR_POP;
-    const bool at_leaf = (uint32_t)cur > (uint32_t)CUR_POP;
+    const bool cur_leaf = (uint32_t)cur > (uint32_t)CUR_POP;
+    const bool at_node = cur >= 0 || cur == CUR_POP || (SPEC && cur_leaf && pend == 0 && sp > 0);
+    const bool at_leaf = cur_leaf || (SPEC && pend != 0);
+    const bool is_done = cur == CUR_DONE && !(SPEC && pend != 0);
     const int n_node = __popcll(__ballot(at_node));
     const int n_leaf = __popcll(__ballot(at_leaf));
-    const int n_done = __popcll(__ballot(cur == CUR_DONE));
-    const int n_act = n_node + n_leaf + n_done;
+    const int n_done = __popcll(__ballot(is_done));
+    const int n_act = SPEC ? __popcll(__ballot(cur != CUR_IDLE)) : n_node + n_leaf + n_done;
     if (n_act == 0) break;                                 // nothing in flight and the refill found nothing: frame done
     if (STATS && lane == 0) st[STAT_LIVE] += (uint32_t)n_act;
 
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (STATS) st[STAT_IT_SHADE]++;
       RT_TICK(0);
       RT_MARK("SHADE_BEGIN");
-      if (cur == CUR_DONE) {
+      if (is_done) {
         double *r = rec;
         asm volatile("" : "+v"(r) : : "memory");            // the record is re-read from memory, never carried in registers
         const bool anyhit = li >= 0;
@@ -367,15 +380,20 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (!exhausted) refill();
       RT_TICK(4);
       RT_MARK("REFILL_END");
-    } else if (n_node * RT_NODE_WEIGHT >= n_leaf) {
+    } else if (n_node * RT_NODE_WEIGHT >= n_leaf * RT_LEAF_WEIGHT) {
       // ================================================= NODE step (BVH.hs:123-143)
       if (STATS) st[STAT_IT_NODE]++;
       RT_TICK(0);
       RT_MARK("NODE_BEGIN");
 #pragma unroll
       for (int it = 0; it < RT_NODE_UNROLL; ++it) {
-        const bool isn = cur >= 0;
         bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
+        if (SPEC) {                                          // postpone a freshly reached leaf and go on with the next stack entry
+          const bool spec = (uint32_t)cur > (uint32_t)CUR_POP && pend == 0 && sp > 0;
+          pend = spec ? cur : pend;
+          pp = pp || spec;
+        }
+        const bool isn = cur >= 0;
         if (STATS && isn) st[STAT_NODES]++;
         bool hL, hR;
         BT tL, tR;
@@ -427,8 +445,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       RT_TICK(0);
       RT_MARK("PRIM_BEGIN");
       {
+        const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
         const bool isl = at_leaf;
-        const int pi = ~cur;
+        const int pi = ~(use_p ? pend : cur);
         DPrim P;
 #pragma unroll
         for (int k = 0; k < 9; ++k) P.d[k] = 0.0;
@@ -463,8 +482,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         tmaxb = h ? tmax_for_boxes<BT>(t) : tmaxb;
         const bool blocked = h && li >= 0;                   // shadow ray: any hit blocks (Light.hs:30-32)
         const bool last = (P.kind & DPRIM_LAST) != 0u;
-        cur = isl ? (blocked ? CUR_DONE : (last ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)
-        bool pp = isl && !blocked && last;
+        if (SPEC) pend = use_p ? ((blocked || last) ? 0 : pend - 1) : (blocked ? 0 : pend);
+        cur = isl ? (blocked ? CUR_DONE : ((last || use_p) ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)
+        bool pp = isl && !use_p && !blocked && last;
         RT_POP2(pp);
       }
       RT_TICK(2);
