@@ -6,7 +6,7 @@
 HIPCC   ?= hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
-RT_MIN_WAVES ?= 3
+RT_MIN_WAVES ?= 4
 
 CORE_SRC := raytracer_amd/csrc/rtcore.hip
 CORE_HDR := $(wildcard raytracer_amd/csrc/*.h) include/rtcore.h

@@ -200,6 +200,11 @@ int  rt_render_tiles_device(rt_scene *scene, const rt_camera *cam, const rt_para
                             void *d_color, void *d_radiance, void *d_prim_id,
                             void *stream, rt_stats *stats);
 
+/* Measurement hook (no counterpart in the reference): sum of the durations, in ms, of the k_render_tiles launches
+ * recorded on this scene since the previous call, taken with HIP events on the stream each launch went to, and
+ * their number (at most 256 are kept).  Blocks until those launches have finished.  bench.py's roofline uses it. */
+int  rt_kernel_times(rt_scene *scene, double *sum_ms, int32_t *n_launches);
+
 /* Scatters one rank's packed device buffer (n_comp doubles per slot) into a full
  * row-major device image of n_comp*W*H doubles, on `stream`. */
 int  rt_untile_device(int32_t width, int32_t height, int32_t rank, int32_t world,

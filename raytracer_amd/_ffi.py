@@ -92,6 +92,7 @@ RTCORE_SYMBOLS = {
     "rt_tile_list": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_int32_p]),
     "rt_render_tiles_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]),
+    "rt_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "rt_untile_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_quantize_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
 }

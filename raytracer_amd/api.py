@@ -197,6 +197,12 @@ class GpuScene:
         F.check(F.core().rt_render(self._h, C.byref(cam), C.byref(p), C.byref(out), C.byref(st)))
         return res, st
 
+    def kernel_times(self):
+        """rt_kernel_times: (sum of ms, number) of the render-kernel launches since the previous call (blocks)."""
+        ms, n = C.c_double(0), C.c_int32(0)
+        F.check(F.core().rt_kernel_times(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def render_tiles_device(self, rank, world, d_color=0, d_radiance=0, d_prim_id=0, stream=0, camera=None, **param_over):
         """rt_render_tiles_device: this rank's tiles into device buffers (raw pointers), asynchronous."""
         p = make_params(self.spec, **param_over)

@@ -1,12 +1,6 @@
-// rt_kernels.h — the wave64 persistent-thread render kernel of the MI355X render core.
-//
-// One wave = one 8x8-pixel tile (lane <-> pixel).  Waves pull tile indices from an atomic
-// counter until the frame (or this rank's tile subset) is exhausted.  Inside a tile every lane
-// runs its own path state machine: it walks its pixel's samples 0..spp-1 in order (so the sum
-// order equals the reference's foldl', RenderWorker.hs:111-114) and never waits for another
-// lane between rays; each trip of the outer loop does exactly ONE BVH query per active lane
-// (closest-hit for camera/bounce rays, any-hit for shadow rays), followed by a short
-// divergent state transition.
+// rt_kernels.h — device code of the MI355X render core: shared structs, the reference's per-ray functions
+// (camera, background, box and primitive tests), the render kernel (rt_render_kernel.h) and the small
+// resolve / un-tile / quantise kernels.
 //
 // Reference semantics restated here (paths relative to /root/reference/app):
 //   camera_ray            Rendering/Camera.hs:47-60, Rendering/RenderWorker.hs:95-106
@@ -42,14 +36,18 @@ struct KFrame {
   uint32_t key0, key1;
   const int32_t *tiles;        // this rank's tile ids, or NULL = all tiles in order
   int32_t n_tiles, tiles_x;
-  int32_t packed;              // 1: outputs indexed by local_tile*64+lane ; 0: row-major full frame
+  int32_t packed;              // 1: outputs indexed by local_tile*64+position ; 0: row-major full frame
   double *out_color, *out_radiance;
   int32_t *out_primid;
-  uint32_t *tile_counter;
-  unsigned long long *stats;   // 8 counters, see STAT_*
-  double *fscratch;            // v3: [grid waves][6][64] doubles, the per-lane bounds of the pending clamp function
+  uint32_t *tile_counter;      // hands out chunks of items
+  unsigned long long *stats;   // STAT_COUNT counters, see STAT_*
+  double *fscratch;            // [grid waves][PR_ROWS][64] doubles: the per-lane path records
   int32_t stack_depth;
-  int32_t top_nodes;           // v5: the first top_nodes internal nodes (top levels, breadth-first) are cached in LDS
+  int32_t top_nodes;           // the first top_nodes internal nodes (top levels, breadth-first) are cached in LDS
+  // one launch covers the local tiles [tile_begin, tile_end) of this rank's list: items = (tile, position, sample)
+  int32_t tile_begin, tile_end;
+  uint32_t n_items;            // (tile_end - tile_begin) * 64 * spp
+  double *samples;             // [n_items][3] radiance of every path of this launch, summed per pixel by k_resolve
 };
 
 enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
@@ -260,18 +258,34 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 
 // ---------------------------------------------------------------- the render kernel
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 3
+#define RT_MIN_WAVES 4
 #endif
-#ifndef RT_KERNEL_VERSION
-#define RT_KERNEL_VERSION 7
-#endif
-#if RT_KERNEL_VERSION == 1
-#include "rt_kernel_v1.h"     // baseline kept for A/B runs: every lane runs whole queries, no vote scheduling (344 ms on C4)
-#else
-#include "rt_kernel_v7.h"     // the product kernel: vote-scheduled NODE / PRIM / SHADE bodies (266 ms on C4)
-#endif
+#include "rt_render_kernel.h"
 
 // ---------------------------------------------------------------- small helper kernels
+// One thread per pixel slot of the launch: the pixel's samples summed in sample order, mean, tone map, gamma
+// (pixelColor / averageColor, RenderWorker.hs:111-114; toneMap / gammaCorrect, Trace.hs:96-105).
+__global__ void k_resolve(const KFrame fr) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;            // local slot within the launch
+  if (j >= (uint32_t)(fr.tile_end - fr.tile_begin) * 64u) return;
+  const uint32_t gt = (uint32_t)fr.tile_begin + (j >> 6), pos = j & 63u;
+  const int tile = fr.tiles ? fr.tiles[gt] : (int)gt;
+  const int px = (tile % fr.tiles_x) * 8 + (int)(pos & 7u), py = (tile / fr.tiles_x) * 8 + (int)(pos >> 3);
+  if (px >= fr.W || py >= fr.H) return;
+  const double *sp = fr.samples + 3 * (size_t)j * (size_t)fr.spp;
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int s = 0; s < fr.spp; ++s) { sx += sp[3 * s]; sy += sp[3 * s + 1]; sz += sp[3 * s + 2]; }
+  const double inv = 1.0 / (double)fr.spp;
+  const d3 avg = mk3(inv * sx, inv * sy, inv * sz);                    // RenderWorker.hs:114
+  const size_t o = 3 * (fr.packed ? (size_t)gt * 64 + pos : (size_t)py * fr.W + px);
+  if (fr.out_radiance) { fr.out_radiance[o] = avg.x; fr.out_radiance[o + 1] = avg.y; fr.out_radiance[o + 2] = avg.z; }
+  if (fr.out_color) {
+    const double e = fr.exposure;
+    const double tc[3] = {avg.x * e / (avg.x * e + 1), avg.y * e / (avg.y * e + 1), avg.z * e / (avg.z * e + 1)};   // Trace.hs:96-101
+    for (int c = 0; c < 3; ++c) fr.out_color[o + c] = pow_gamma(tc[c], fr.gamma);                                 // Trace.hs:103-105
+  }
+}
+
 __global__ void k_untile(const int32_t *tiles, int n_tiles, int tiles_x, int W, int H, int n_comp,
                          const double *packed, double *image) {
   const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,4 +1,4 @@
-// rt_kernel_v7.h — the render kernel as a VOTE-SCHEDULED per-lane state machine, cold path state out of
+// rt_render_kernel.h — the render kernel as a VOTE-SCHEDULED per-lane state machine, cold path state out of
 // the register file (v3), and LANES AS WORKERS that pull pixels from a pool (v4).
 //
 // v1 ran one complete BVH query per lane per outer trip, so every lane waited for the longest
@@ -43,6 +43,14 @@
 // therefore STRAIGHT-LINE predicated code: selects instead of nested ifs, no early exits in the triangle test,
 // two inline predicated pops (a lane whose two popped entries were both culled continues in state CUR_POP),
 // spheres/planes behind a wave-uniform branch that all-triangle leaves never take.
+//
+// v8: the work item is ONE PATH (pixel, sample), not a pixel.  A lane used to own a pixel for all its spp samples
+// (25 ms of work on the metric scene), so the end of a frame - or of one GPU's share of it when the frame is cut
+// over 8 GPUs - drained for one pixel-time with half the lanes idle.  Now lanes pull items `q = (tile, position in
+// tile, sample)` from the wave's pool; consecutive items are consecutive samples of one pixel, so a freshly filled
+// wave traces 64 nearly identical primary rays.  Each path writes its radiance to samples[q] (24 B; 5 GB for
+// 1080p x 100 spp - HBM has 288 GB) and k_resolve sums a pixel's samples IN SAMPLE ORDER (the reference's foldl',
+// RenderWorker.hs:111-114), so the frame is bit-identical to the pixel-per-lane version and to any sharding.
 #pragma once
 #define CUR_IDLE ((int)0x80000000)
 #define CUR_DONE ((int)0x80000001)
@@ -58,8 +66,11 @@
 #else
 #define RT_MARK(name) do { } while (0)
 #endif
+#ifndef RT_CHUNK
+#define RT_CHUNK 1024u      // items a wave takes from the global counter at a time (multiple of 64)
+#endif
 #ifndef RT_BLOCK_THREADS
-#define RT_BLOCK_THREADS 768
+#define RT_BLOCK_THREADS (256 * RT_MIN_WAVES)   // one workgroup per CU
 #endif
 
 #ifndef RT_NODE_WEIGHT
@@ -93,11 +104,10 @@ __device__ __attribute__((noinline)) double pow_gamma(double c, double g) { retu
 
 template <typename BT, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
-  extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: [entry][lane] stack + [3][lane] pixel sums
+  extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: [entry][lane] stack
   const int lane = threadIdx.x & 63;
   const float4 *lnodes = (const float4 *)lds_all;          // 4 x float4 per cached FP32 node
-  uint2 *stack = lds_all + (size_t)fr.top_nodes * 8 + (size_t)(threadIdx.x >> 6) * (fr.stack_depth + 3) * 64 + lane;
-  double *lsum = (double *)(stack + (size_t)fr.stack_depth * 64);       // lsum[k*64], k = 0..2
+  uint2 *stack = lds_all + (size_t)fr.top_nodes * 8 + (size_t)(threadIdx.x >> 6) * fr.stack_depth * 64 + lane;
   double *rec = fr.fscratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PR_ROWS * 64 + lane;
   const DNode<BT> *nodes = (const DNode<BT> *)sc.nodes;
   const double inf = __builtin_huge_val();
@@ -114,9 +124,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   }
   __syncthreads();
 
-  // ---- per-lane pixel (the lane's current work item) and traversal state (registers)
+  // ---- per-lane work item and traversal state (registers)
   uint32_t pixel = 0;                                      // row*W + col, also the RNG key
-  uint32_t slot = 0;                                       // where this pixel's outputs go
+  uint32_t item = 0;                                       // index of this path in fr.samples (its sample number is in the record)
   d3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
   BoxRay<BT> br;
   BT tmaxb = (BT)0;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   // the reference; nodes visited before the postponed leaf has narrowed the interval are a superset of the reference's.
   constexpr bool SPEC = (RT_SPECULATE != 0) && sizeof(BT) == 4;
   int pend = 0;
-  // ---- wave-uniform pool of pixel slots [pool_next, pool_end) in tile order
+  // ---- wave-uniform pool of items [pool_next, pool_end)
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
 
@@ -161,61 +171,49 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
     }                                                                                \
     cur = (p_) ? CUR_POP : cur;                                                      \
   } while (0)
-#define RT_WRITE_PIXEL()                                                                                                   \
-  do {                                                                                                                     \
-    const d3 avg_ = (1.0 / (double)fr.spp) * mk3(lsum[0], lsum[64], lsum[128]);       /* RenderWorker.hs:114 */            \
-    const double e_x = fr.exposure;                                                                                        \
-    const d3 toned_ = mk3(avg_.x * e_x / (avg_.x * e_x + 1), avg_.y * e_x / (avg_.y * e_x + 1), avg_.z * e_x / (avg_.z * e_x + 1)); /* Trace.hs:96-101 */ \
-    const size_t o_ = 3 * (size_t)slot;                                                                                    \
-    if (fr.out_radiance) { fr.out_radiance[o_] = avg_.x; fr.out_radiance[o_ + 1] = avg_.y; fr.out_radiance[o_ + 2] = avg_.z; } \
-    if (fr.out_color) {                                                                                                    \
-      const double tc_[3] = {toned_.x, toned_.y, toned_.z};                                                                \
-      _Pragma("nounroll") for (int c_ = 0; c_ < 3; ++c_) fr.out_color[o_ + c_] = pow_gamma(tc_[c_], fr.gamma);             \
-    }                                                                                                                      \
-  } while (0)
 
-  // Gives every idle lane its next pixel slot.  All lanes of the wave run this (uniform control flow).
+  // Gives every idle lane its next item.  All lanes of the wave run this (uniform control flow).
+  // item q of this launch -> local tile q / (64 spp), position in the 8x8 tile (q / spp) % 64, sample q % spp.
+  const uint32_t per_tile = 64u * (uint32_t)fr.spp;
   auto refill = [&]() {
     for (;;) {
       const unsigned long long need = __ballot(cur == CUR_IDLE);
       if (need == 0ull) break;
-      if (pool_next == pool_end) {                         // pool empty: take the next tile from the global counter
-        uint32_t ti = 0;
-        if (lane == 0) ti = atomicAdd(fr.tile_counter, 1u);
-        ti = __builtin_amdgcn_readfirstlane(ti);
-        if (ti >= (uint32_t)fr.n_tiles) { exhausted = true; break; }
-        pool_next = ti * 64u; pool_end = pool_next + 64u;
+      if (pool_next == pool_end) {                         // pool empty: take the next chunk from the global counter
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(fr.tile_counter, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if ((unsigned long long)c * RT_CHUNK >= (unsigned long long)fr.n_items) { exhausted = true; break; }
+        pool_next = c * RT_CHUNK;
+        pool_end = fr.n_items - pool_next < RT_CHUNK ? fr.n_items : pool_next + RT_CHUNK;
       }
       const uint32_t avail = pool_end - pool_next;
       const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));   // my index among the idle lanes
       const uint32_t n_need = (uint32_t)__popcll(need);
       if (cur == CUR_IDLE && rank < avail) {
-        const uint32_t q = pool_next + rank;               // pixel slot q = local tile * 64 + position in the 8x8 tile
-        const uint32_t lt = q >> 6, pos = q & 63u;
-        const int tile = fr.tiles ? fr.tiles[lt] : (int)lt;
+        const uint32_t q = pool_next + rank;
+        const uint32_t lt = q / per_tile, rem = q - lt * per_tile;
+        const uint32_t pos = rem / (uint32_t)fr.spp, smp = rem - pos * (uint32_t)fr.spp;
+        const uint32_t gt = (uint32_t)fr.tile_begin + lt;  // index into this rank's tile list
+        const int tile = fr.tiles ? fr.tiles[gt] : (int)gt;
         const int px = (tile % fr.tiles_x) * 8 + (int)(pos & 7u);
         const int py = (tile / fr.tiles_x) * 8 + (int)(pos >> 3);
-        if (px < fr.W && py < fr.H) {                      // slots outside the image are consumed and dropped
+        if (px < fr.W && py < fr.H) {                      // items outside the image are consumed and dropped
           pixel = (uint32_t)(py * fr.W + px);
-          slot = fr.packed ? q : pixel;
-          lsum[0] = 0.0; lsum[64] = 0.0; lsum[128] = 0.0;
-          if (fr.out_primid) fr.out_primid[slot] = -1;
+          item = q;
+          if (smp == 0u && fr.out_primid) fr.out_primid[fr.packed ? gt * 64u + pos : pixel] = -1;
+          camera_ray(fr, px, py, pixel, smp, ro, rd);
           if (fr.maxb > 0) {
-            camera_ray(fr, px, py, pixel, 0u, ro, rd);
             rec_st(rec, PR_ATT, mk3(1, 1, 1)); rec_st(rec, PR_FA, mk3(0, 0, 0));
             rec_st(rec, PR_FL, mk3(-inf, -inf, -inf)); rec_st(rec, PR_FH, mk3(inf, inf, inf));
-            rec_sti(rec, PR_SB, 0, 0);
+            rec_sti(rec, PR_SB, (int)smp, 0);
             li = -1;
             RT_BEGIN_QUERY(RT_TMAX);
           } else {
-            // traceLoop _ 0: every sample is the background along its camera ray (Trace.hs:22); nothing is traced
-            for (int s = 0; s < fr.spp; ++s) {
-              d3 o_, d_;
-              camera_ray(fr, px, py, pixel, (uint32_t)s, o_, d_);
-              const d3 b_ = background(sc, d_);
-              lsum[0] += b_.x; lsum[64] += b_.y; lsum[128] += b_.z;
-            }
-            RT_WRITE_PIXEL();
+            // traceLoop _ 0: the sample is the background along its camera ray (Trace.hs:22); nothing is traced
+            const d3 b_ = background(sc, rd);
+            double *o_ = fr.samples + 3 * (size_t)q;
+            o_[0] = b_.x; o_[1] = b_.y; o_[2] = b_.z;
           }
         }
       }
@@ -257,7 +255,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             need_finish = true;
           } else {
             const int2 sb = rec_ldi(r, PR_SB);
-            if (sb.x == 0 && sb.y == 0 && fr.out_primid) fr.out_primid[slot] = sc.prim_ids[best];
+            if (sb.x == 0 && sb.y == 0 && fr.out_primid)   // primary hit of sample 0: the pixel's id (slot of a packed output: tile*64 + position)
+              fr.out_primid[fr.packed ? (uint32_t)fr.tile_begin * 64u + item / (uint32_t)fr.spp : pixel] = sc.prim_ids[best];
             const DPrim P = sc.prims[best];
             const uint32_t kind = P.kind & DPRIM_KIND_MASK;
             const d3 hp = ro + best_t * rd;                  // R.at ray t
@@ -346,32 +345,16 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           li = -1;
           if (sb.y + 1 >= fr.maxb) { need_ray0 = true; need_finish = true; }     // depth 0: background along ray0, :22
         }
-        if (need_finish) {
-          // ONE camera_ray and ONE background call site (their libm-heavy bodies are inlined once): pass 0 regenerates
-          // the primary ray of this sample when the depth ran out, pass 1 starts the next sample's path.
-          const int s_cur = rec_ldi(r, PR_SB).x;
-#pragma nounroll
-          for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 0 ? need_ray0 : (s_cur + 1 < fr.spp)) {
-              d3 o_, d_;
-              camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)(s_cur + pass), o_, d_);
-              if (pass == 0) bgdir = d_; else { ro = o_; rd = d_; }
-            }
-            if (pass == 0) {
-              const d3 T = rec_ld(r, PR_ATT) * background(sc, bgdir);
-              const d3 R = clamp3(T + rec_ld(r, PR_FA), rec_ld(r, PR_FL), rec_ld(r, PR_FH));
-              lsum[0] += R.x; lsum[64] += R.y; lsum[128] += R.z;
-            }
+        if (need_finish) {                                   // path end: its radiance goes to the per-sample buffer
+          if (need_ray0) {                                   // depth ran out: background along the PRIMARY ray (Trace.hs:22), regenerated
+            d3 o_;
+            camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)rec_ldi(r, PR_SB).x, o_, bgdir);
           }
-          if (s_cur + 1 < fr.spp) {
-            rec_st(r, PR_ATT, mk3(1, 1, 1)); rec_st(r, PR_FA, mk3(0, 0, 0));
-            rec_st(r, PR_FL, mk3(-inf, -inf, -inf)); rec_st(r, PR_FH, mk3(inf, inf, inf));
-            rec_sti(r, PR_SB, s_cur + 1, 0);
-            li = -1; q_tmax = RT_TMAX;
-          } else {
-            RT_WRITE_PIXEL();                                // last sample of this pixel: tone map, gamma, store
-            cur = CUR_IDLE;                                  // the lane is free: it pulls its next pixel in the refill below
-          }
+          const d3 T = rec_ld(r, PR_ATT) * background(sc, bgdir);
+          const d3 R = clamp3(T + rec_ld(r, PR_FA), rec_ld(r, PR_FL), rec_ld(r, PR_FH));
+          double *o_ = fr.samples + 3 * (size_t)item;
+          o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
+          cur = CUR_IDLE;                                    // the lane is free: it pulls its next item in the refill below
         }
         if (cur != CUR_IDLE) RT_BEGIN_QUERY(q_tmax);
       }
@@ -493,7 +476,6 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 #undef RT_BEGIN_QUERY
 #undef RT_POP
 #undef RT_POP2
-#undef RT_WRITE_PIXEL
 
   if (STATS && lane == 0) {
     for (int k = 0; k < 5; ++k) atomicAdd(fr.stats + STAT_T_VOTE + k, tacc[k]);

@@ -81,8 +81,10 @@ struct rt_scene {
   // per-launch scratch
   uint32_t *d_counter = nullptr;
   unsigned long long *d_stats = nullptr;
-  double *d_fscratch = nullptr;         // per resident wave: bounds of the pending clamp function (rt_kernel_v3.h)
+  double *d_fscratch = nullptr;         // per resident wave: the lanes' path records (rt_render_kernel.h)
   size_t fscratch_waves = 0;
+  double *d_samples = nullptr;          // radiance of every path of one launch, [item][3]
+  size_t samples_cap = 0;               // bytes
   // cached outputs of rt_render
   size_t cap_px = 0;
   double *d_color = nullptr, *d_radiance = nullptr;
@@ -92,6 +94,10 @@ struct rt_scene {
   int tl_w = -1, tl_h = -1, tl_rank = -1, tl_world = -1, tl_n = 0;
   int32_t *d_tiles = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // HIP event pairs around the k_render_tiles launches since the last rt_kernel_times call (measurement hook)
+  static constexpr int KT_RING = 256;
+  std::vector<hipEvent_t> kt_events;    // 2 per launch, created on first use
+  int kt_pending = 0;
 };
 
 extern "C" {
@@ -121,8 +127,9 @@ void rt_scene_destroy(rt_scene *s) {
   if (!s) return;
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
   (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_sky);
-  (void)hipFree(s->d_counter); (void)hipFree(s->d_stats); (void)hipFree(s->d_fscratch);
+  (void)hipFree(s->d_counter); (void)hipFree(s->d_stats); (void)hipFree(s->d_fscratch); (void)hipFree(s->d_samples);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_tiles);
+  for (hipEvent_t e : s->kt_events) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -372,17 +379,19 @@ static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
   return RT_OK;
 }
 
+// One frame (or one rank's share of it) = one or more launches of k_render_tiles + k_resolve.  A launch covers a
+// range of the rank's tiles whose per-path radiance fits the sample buffer; normally that is the whole frame
+// (1080p x 100 spp: 5 GB of 288 GB).  The split never changes a result: k_resolve sums in sample order.
 template <typename BT, bool STATS>
 static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   KFrame fr = fr_in;
-#if RT_KERNEL_VERSION != 1
-  const int threads = RT_BLOCK_THREADS;
-#else
-  const int threads = 256;
-#endif
-#if RT_KERNEL_VERSION != 1
-  // LDS: per wave the stack and 3 rows of pixel sums; what is left of 160 KB (one workgroup per CU) caches top BVH levels
-  const size_t lds_waves = (size_t)(threads / 64) * (fr.stack_depth + 3) * 64 * sizeof(uint2);
+  // One workgroup per CU, RT_MIN_WAVES waves per SIMD; deep trees (long per-lane stacks) get fewer waves so that the
+  // stacks still fit the CU's LDS.  What is left of 160 KB caches the top BVH levels.
+  const size_t stack_bytes = (size_t)fr.stack_depth * 64 * sizeof(uint2);
+  int wpb = RT_BLOCK_THREADS / 64;
+  while (wpb > 4 && (size_t)wpb * stack_bytes > 150 * 1024) wpb -= 4;
+  const int threads = wpb * 64;
+  const size_t lds_waves = (size_t)wpb * stack_bytes;
   fr.top_nodes = 0;
   if (sizeof(BT) == 4 && lds_waves < 156 * 1024) {
     size_t room = (156 * 1024 - lds_waves) / sizeof(DNode<float>);
@@ -393,33 +402,73 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   }
   size_t lds = lds_waves + (size_t)fr.top_nodes * sizeof(DNode<float>);
   if (const char *pad = getenv("RT_LDS_BYTES")) lds = std::max(lds, (size_t)atol(pad));   // experiment knob: caps blocks per CU
-#else
-  const size_t lds = (size_t)(threads / 64) * fr.stack_depth * 64 * sizeof(uint2);
-#endif
   if (lds > 160 * 1024) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
   auto kern = k_render_tiles<BT, STATS>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
   per_cu = std::max(1, per_cu);
-  const int want = (fr.n_tiles + threads / 64 - 1) / (threads / 64);
-  const int grid = std::max(1, std::min(want, g_ctx.n_cu * per_cu));
-#if RT_KERNEL_VERSION != 1
-  const size_t waves = (size_t)grid * (threads / 64);
+
+  // tiles per launch from the sample-buffer budget
+  const size_t bytes_per_tile = (size_t)64 * fr.spp * 3 * sizeof(double);
+  const size_t max_tiles_32 = (size_t)0x7fffffff / ((size_t)64 * fr.spp);     // item indices are 32-bit
+  if (max_tiles_32 == 0) return fail(RT_ERR_UNSUPPORTED, "samplesPerPixel %d too large", fr.spp);
+  size_t tpp = std::min<size_t>((size_t)fr.n_tiles, max_tiles_32);
+  if (tpp * bytes_per_tile > s->samples_cap) {
+    size_t budget;
+    if (const char *env = getenv("RT_SAMPLE_BUDGET_MB")) budget = (size_t)atol(env) << 20;   // tests: forces several launches
+    else {
+      size_t fre = 0, tot = 0;
+      HIP_TRY(hipMemGetInfo(&fre, &tot));
+      budget = std::min<size_t>((fre + s->samples_cap) / 2, (size_t)64 << 30);
+    }
+    tpp = std::max<size_t>(1, std::min(tpp, budget / bytes_per_tile));
+    if (tpp * bytes_per_tile > s->samples_cap) {            // grows only on the first launch / a larger frame
+      HIP_TRY(hipStreamSynchronize(stream));
+      (void)hipFree(s->d_samples); s->d_samples = nullptr; s->samples_cap = 0;
+      if (hipMalloc((void **)&s->d_samples, tpp * bytes_per_tile) != hipSuccess)
+        return fail(RT_ERR_OOM, "sample buffer of %zu bytes (%zu tiles x %d spp)", tpp * bytes_per_tile, tpp, fr.spp);
+      s->samples_cap = tpp * bytes_per_tile;
+    }
+  }
+  fr.samples = s->d_samples;
+
+  const size_t waves_first = (tpp * 64 * (size_t)fr.spp + 63) / 64;           // wave-loads of items in the largest launch
+  const int grid_max = (int)std::max<size_t>(1, std::min<size_t>((waves_first + wpb - 1) / wpb, (size_t)g_ctx.n_cu * per_cu));
+  const size_t waves = (size_t)grid_max * wpb;
   if (waves > s->fscratch_waves) {      // grows only on the first launch / a larger grid; never inside a steady-state loop
     HIP_TRY(hipStreamSynchronize(stream));
     (void)hipFree(s->d_fscratch); s->d_fscratch = nullptr; s->fscratch_waves = 0;
-    if (hipMalloc((void **)&s->d_fscratch, waves * PR_ROWS * 64 * sizeof(double)) != hipSuccess) return fail(RT_ERR_OOM, "clamp-bounds scratch for %zu waves", waves);
+    if (hipMalloc((void **)&s->d_fscratch, waves * PR_ROWS * 64 * sizeof(double)) != hipSuccess) return fail(RT_ERR_OOM, "path records for %zu waves", waves);
     s->fscratch_waves = waves;
   }
   fr.fscratch = s->d_fscratch;
-#endif
-  HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
   if (STATS) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
   KScene ks = s->ks;
   if (sizeof(BT) == 8) ks.nodes = s->d_nodes64;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, ks, fr);
-  HIP_TRY(hipGetLastError());
+  for (size_t t0 = 0; t0 < (size_t)fr.n_tiles; t0 += tpp) {
+    fr.tile_begin = (int32_t)t0;
+    fr.tile_end = (int32_t)std::min<size_t>((size_t)fr.n_tiles, t0 + tpp);
+    const size_t slots = (size_t)(fr.tile_end - fr.tile_begin) * 64;
+    fr.n_items = (uint32_t)(slots * fr.spp);
+    const size_t want = ((size_t)fr.n_items / 64 + wpb - 1) / wpb;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)grid_max));
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
+    const bool timed = s->kt_pending < rt_scene::KT_RING;
+    if (timed) {
+      while ((int)s->kt_events.size() < 2 * (s->kt_pending + 1)) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->kt_events.push_back(e);
+      }
+      HIP_TRY(hipEventRecord(s->kt_events[2 * s->kt_pending], stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, ks, fr);
+    HIP_TRY(hipGetLastError());
+    if (timed) { HIP_TRY(hipEventRecord(s->kt_events[2 * s->kt_pending + 1], stream)); ++s->kt_pending; }
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, fr);
+    HIP_TRY(hipGetLastError());
+  }
   return RT_OK;
 }
 
@@ -547,6 +596,21 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p
       if ((rc = read_stats(s, stats))) return rc;
     }
   }
+  return RT_OK;
+}
+
+int rt_kernel_times(rt_scene *s, double *sum_ms, int32_t *n_launches) {
+  if (!s || !sum_ms || !n_launches) return fail(RT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  double sum = 0;
+  for (int i = 0; i < s->kt_pending; ++i) {
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(s->kt_events[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, s->kt_events[2 * i], s->kt_events[2 * i + 1]));
+    sum += ms;
+  }
+  *sum_ms = sum; *n_launches = s->kt_pending;
+  s->kt_pending = 0;
   return RT_OK;
 }
 

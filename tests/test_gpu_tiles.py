@@ -43,3 +43,19 @@ def test_quantize_device_matches_host_rule(need_gpu):
     F.check(F.core().rt_quantize_device(C.c_void_p(c.data_ptr()), C.c_void_p(q.data_ptr()), 8, None))
     torch.cuda.synchronize()
     assert q.cpu().tolist() == [0, 127, 255, 255, 0, 255, 0, 0]      # truncate(c*255.999), clamped to 0..255
+
+
+def test_sample_buffer_passes_do_not_change_the_frame(need_gpu, monkeypatch):
+    """A frame whose per-path radiance does not fit the sample buffer is rendered in several launches (tile ranges);
+    k_resolve sums every pixel's samples in sample order, so the split is invisible.  1 MB holds 6 tiles at 112 spp."""
+    spec = scenes.c3_blob988(width=130, height=75, spp=112)
+    g = api.GpuScene(spec)
+    one, _ = g.render(want=("color", "radiance", "prim_id"))
+    g.close()
+    monkeypatch.setenv("RT_SAMPLE_BUDGET_MB", "1")
+    g = api.GpuScene(spec)                                   # a new scene: its sample buffer is sized by the 1-MB budget
+    many, st = g.render(want=("color", "radiance", "prim_id"), collect_stats=1)
+    g.close()
+    for k in ("color", "radiance", "prim_id"):
+        assert np.array_equal(one[k], many[k]), k
+    assert st.paths == 130 * 75 * 112
