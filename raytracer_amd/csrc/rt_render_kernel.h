@@ -69,6 +69,9 @@
 #ifndef RT_CHUNK
 #define RT_CHUNK 1024u      // items a wave takes from the global counter at a time (multiple of 64)
 #endif
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16    // idle lanes are given new items once this many wait (or none is live): the refill costs the whole wave
+#endif
 #ifndef RT_BLOCK_THREADS
 #define RT_BLOCK_THREADS (256 * RT_MIN_WAVES)   // one workgroup per CU
 #endif
@@ -98,6 +101,15 @@ RT_DEV int2 rec_ldi(const double *r, int row) { return *(const int2 *)(r + row *
 RT_DEV void rec_sti(double *r, int row, int a, int b) { *(int2 *)(r + row * 64) = make_int2(a, b); }
 #endif
 
+
+// n / d for n < 2^24 with rcp = 1.0f / d: float estimate, exact after the correction steps
+RT_DEV uint32_t fastdiv24(uint32_t n, uint32_t d, float rcp) {
+  uint32_t q = (uint32_t)((float)n * rcp);
+  int32_t r = (int32_t)(n - q * d);
+  while (r < 0) { --q; r += (int32_t)d; }
+  while (r >= (int32_t)d) { ++q; r -= (int32_t)d; }
+  return q;
+}
 
 // gamma correction c ** gamma (Trace.hs:103-105), out of line: the FP64 pow body must not set the kernel's register budget
 __device__ __attribute__((noinline)) double pow_gamma(double c, double g) { return pow(c, g); }
@@ -174,7 +186,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 
   // Gives every idle lane its next item.  All lanes of the wave run this (uniform control flow).
   // item q of this launch -> local tile q / (64 spp), position in the 8x8 tile (q / spp) % 64, sample q % spp.
+  // The chunk start is decomposed once per chunk (wave-uniform); a lane's item then needs only small divisions.
   const uint32_t per_tile = 64u * (uint32_t)fr.spp;
+  const float rcp_spp = 1.0f / (float)fr.spp, rcp_tx = 1.0f / (float)fr.tiles_x;
+  const bool small_div = fr.spp < (1 << 22) && (uint32_t)fr.tiles_x * (uint32_t)((fr.H + 7) / 8) < (1u << 24);
+  uint32_t pool_base = 0, pool_lt0 = 0, pool_pos0 = 0, pool_s0 = 0;
   auto refill = [&]() {
     for (;;) {
       const unsigned long long need = __ballot(cur == CUR_IDLE);
@@ -186,18 +202,27 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         if ((unsigned long long)c * RT_CHUNK >= (unsigned long long)fr.n_items) { exhausted = true; break; }
         pool_next = c * RT_CHUNK;
         pool_end = fr.n_items - pool_next < RT_CHUNK ? fr.n_items : pool_next + RT_CHUNK;
+        pool_base = pool_next;
+        pool_lt0 = pool_base / per_tile;
+        const uint32_t rem0 = pool_base - pool_lt0 * per_tile;
+        pool_pos0 = rem0 / (uint32_t)fr.spp;
+        pool_s0 = rem0 - pool_pos0 * (uint32_t)fr.spp;
       }
       const uint32_t avail = pool_end - pool_next;
       const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));   // my index among the idle lanes
       const uint32_t n_need = (uint32_t)__popcll(need);
       if (cur == CUR_IDLE && rank < avail) {
         const uint32_t q = pool_next + rank;
-        const uint32_t lt = q / per_tile, rem = q - lt * per_tile;
-        const uint32_t pos = rem / (uint32_t)fr.spp, smp = rem - pos * (uint32_t)fr.spp;
+        const uint32_t t_ = pool_s0 + (q - pool_base);     // < spp + RT_CHUNK
+        const uint32_t dpos = small_div ? fastdiv24(t_, (uint32_t)fr.spp, rcp_spp) : t_ / (uint32_t)fr.spp;
+        const uint32_t smp = t_ - dpos * (uint32_t)fr.spp;
+        const uint32_t p_ = pool_pos0 + dpos;
+        const uint32_t lt = pool_lt0 + (p_ >> 6), pos = p_ & 63u;
         const uint32_t gt = (uint32_t)fr.tile_begin + lt;  // index into this rank's tile list
-        const int tile = fr.tiles ? fr.tiles[gt] : (int)gt;
-        const int px = (tile % fr.tiles_x) * 8 + (int)(pos & 7u);
-        const int py = (tile / fr.tiles_x) * 8 + (int)(pos >> 3);
+        const uint32_t tile = fr.tiles ? (uint32_t)fr.tiles[gt] : gt;
+        const uint32_t trow = small_div ? fastdiv24(tile, (uint32_t)fr.tiles_x, rcp_tx) : tile / (uint32_t)fr.tiles_x;
+        const int px = (int)(tile - trow * (uint32_t)fr.tiles_x) * 8 + (int)(pos & 7u);
+        const int py = (int)trow * 8 + (int)(pos >> 3);
         if (px < fr.W && py < fr.H) {                      // items outside the image are consumed and dropped
           pixel = (uint32_t)(py * fr.W + px);
           item = q;
@@ -223,9 +248,12 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = STATS ? clock64() : 0ull;   // vote, node, prim, shade, refill
 #define RT_TICK(k) do { if (STATS) { const unsigned long long n_ = clock64(); tacc[k] += n_ - tlast; tlast = n_; } } while (0)
-  refill();
-  RT_TICK(4);
   for (;;) {
+    if (!exhausted && __popcll(__ballot(cur == CUR_IDLE)) >= RT_REFILL_MIN) {   // all 64 idle at the start
+      RT_TICK(0);
+      refill();
+      RT_TICK(4);
+    }
     const bool cur_leaf = (uint32_t)cur > (uint32_t)CUR_POP;
     const bool at_node = cur >= 0 || cur == CUR_POP || (SPEC && cur_leaf && pend == 0 && sp > 0);
     const bool at_leaf = cur_leaf || (SPEC && pend != 0);
@@ -360,8 +388,6 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       }
       RT_MARK("SHADE_END");
       RT_TICK(3);
-      if (!exhausted) refill();
-      RT_TICK(4);
       RT_MARK("REFILL_END");
     } else if (n_node * RT_NODE_WEIGHT >= n_leaf * RT_LEAF_WEIGHT) {
       // ================================================= NODE step (BVH.hs:123-143)
