@@ -69,6 +69,9 @@
 #ifndef RT_CHUNK
 #define RT_CHUNK 1024u      // items a wave takes from the global counter at a time (multiple of 64)
 #endif
+#ifndef RT_PRIM_UNROLL
+#define RT_PRIM_UNROLL 1    // primitive tests per PRIM trip
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16    // idle lanes are given new items once this many wait (or none is live): the refill costs the whole wave
 #endif
@@ -453,9 +456,10 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (STATS) st[STAT_IT_PRIM]++;
       RT_TICK(0);
       RT_MARK("PRIM_BEGIN");
-      {
+#pragma unroll
+      for (int it = 0; it < RT_PRIM_UNROLL; ++it) {
         const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
-        const bool isl = at_leaf;
+        const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_POP;
         const int pi = ~(use_p ? pend : cur);
         DPrim P;
 #pragma unroll
