@@ -125,6 +125,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_total / (ms_per_step * 1e-3) / 1e6
 
+    t_ppm = None
+    if rank == 0:
+        # end-to-end extras (untimed for `value`): frame to host + the reference's P3 text body (ImageGenerator.hs:97-115)
+        from raytracer_amd import _ffi as F
+        t1 = time.perf_counter()
+        host_rgb = rgb8.cpu().numpy()
+        cap = 12 * W * H + 64
+        buf = C.create_string_buffer(cap)
+        n = F.host().rth_format_ppm(W, H, host_rgb.ctypes.data_as(F.c_uint8_p), buf, cap)
+        t_ppm = time.perf_counter() - t1
+        if n <= 0:
+            raise SystemExit("rth_format_ppm failed")
     if rank == 0:
         achieved = my_alg_bytes / (kernel_ms * 1e-3) / 1e9        # rank 0's kernel: algorithmic GB/s
         traffic = None
@@ -144,7 +156,8 @@ def main():
                                    f"leafThreshold {spec.leaf_threshold}, bvhMaxDepth {spec.bvh_max_depth}, 1 point light",
                        "parallelism": f"tiles{world}", "rays_per_frame": rays_total, "paths_per_frame": tot[7],
                        "frame_time_s": round(ms_per_step * 1e-3, 5), "kernel_ms": round(kernel_ms_max, 3),
-                       "setup_s": round(t_setup, 3)},
+                       "setup_s": round(t_setup, 3), "d2h_plus_ppm_text_s": round(t_ppm, 3),
+                       "end_to_end_s": round(t_setup + ms_per_step * 1e-3 + t_ppm, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "k_render_tiles<float,false>", "kernel_ms": round(kernel_ms, 3), "launches": k_n,

@@ -73,7 +73,7 @@
 #define RT_PRIM_UNROLL 1    // primitive tests per PRIM trip
 #endif
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 16    // idle lanes are given new items once this many wait (or none is live): the refill costs the whole wave
+#define RT_REFILL_MIN 24    // idle lanes are given new items once this many wait (or none is live): the refill costs the whole wave
 #endif
 #ifndef RT_BLOCK_THREADS
 #define RT_BLOCK_THREADS (256 * RT_MIN_WAVES)   // one workgroup per CU
@@ -86,10 +86,10 @@
 #define RT_LEAF_WEIGHT 1
 #endif
 #ifndef RT_SHADE_NUM
-#define RT_SHADE_NUM 1      // run the SHADE body once >= NUM/DEN of the wave's live lanes wait for it
+#define RT_SHADE_NUM 5      // run the SHADE body once >= NUM/DEN of the wave's live lanes wait for it (measured 1/2: 159 ms, 5/8: 156.5, 7/8: 167)
 #endif
 #ifndef RT_SHADE_DEN
-#define RT_SHADE_DEN 2
+#define RT_SHADE_DEN 8
 #endif
 
 // rows of the per-lane path record (doubles; 64 lanes per row)
