@@ -139,12 +139,13 @@ def main():
             raise SystemExit("rth_format_ppm failed")
     if rank == 0:
         achieved = my_alg_bytes / (kernel_ms * 1e-3) / 1e9        # rank 0's kernel: algorithmic GB/s
-        traffic = None
+        traffic, pmc = None, {}
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured HBM bytes per launch (rocprofv3 --pmc), if committed
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(f"{args.workload}_{W}x{H}_spp{spec.spp}_n{world}")
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
+                pmc = {k: rec[k] for k in ("valu_busy_frac", "valu_lane_utilisation", "l2_hit_rate") if rec and k in rec}
             except Exception:
                 traffic = None
         out = {
@@ -165,7 +166,11 @@ def main():
                          "algorithmic_bytes_per_launch": my_alg_bytes,
                          "bytes_per_ray": round(my_alg_bytes / max(1, mine[0] + mine[1]), 1),
                          "nodes_per_ray": round(mine[2] / max(1, mine[0] + mine[1]), 2),
-                         "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / max(1, mine[0] + mine[1]), 2)},
+                         "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / max(1, mine[0] + mine[1]), 2),
+                         "pmc": pmc,
+                         "note": "frac > 1 is expected: the scene (6 MB) is served from LDS/L1/L2, so the algorithmic bytes never "
+                                 "reach HBM; measured HBM-side traffic is `traffic`. The kernel is VALU-issue bound (pmc.valu_busy_frac, "
+                                 "from the committed rocprofv3 passes), see DESIGN.md section 7"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_threads)

@@ -97,6 +97,14 @@ def main():
         if "hbm_read_bytes_x2_gfx950" in d:
             traffic[workload_key] = {"hbm_bytes_per_launch": int(d["hbm_read_bytes_x2_gfx950"] + d.get("hbm_write_bytes", 0)),
                                      "source": f"profiles/{tag}_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"}
+            # the limiter that matters for this kernel: VALU issue.  SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of a
+            # wave's life spent issuing VALU work; times the resident waves per SIMD = how busy each SIMD's VALU is.
+            if "frac_wave_cycles_valu(SQ_ACTIVE_INST_VALU)" in d and "resident_waves_per_simd" in d:
+                traffic[workload_key]["valu_busy_frac"] = round(d["frac_wave_cycles_valu(SQ_ACTIVE_INST_VALU)"] * d["resident_waves_per_simd"], 4)
+            if "valu_lane_utilisation" in d:
+                traffic[workload_key]["valu_lane_utilisation"] = round(d["valu_lane_utilisation"], 4)
+            if "l2_hit_rate" in d:
+                traffic[workload_key]["l2_hit_rate"] = round(d["l2_hit_rate"], 4)
     json.dump(traffic, open(tf, "w"), indent=1, sort_keys=True)
     print(open(os.path.join(dst, f"{tag}_summary.md")).read())
 
