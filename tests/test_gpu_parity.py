@@ -161,3 +161,15 @@ def test_error_paths(need_gpu):
     a["node_child"][0, 1] = 999          # dangling child index must be rejected on the host, not fault the GPU
     with pytest.raises(F.RtError):
         api.GpuScene(spec, desc_arrays=a)
+
+
+def test_arithmetic_is_contraction_free(need_gpu):
+    """Stricter than the north_star bar, and deliberately so: librtcore is built with -ffp-contract=off because the
+    reference (GHC) forms no FMAs and hit decisions on shared edges/vertices hang on the last bit of t, u, v.  With it
+    the kernel's FP64 arithmetic rounds like the oracle's: no primitive-id mismatch at all (the 33x17 frame has a
+    centre ray through a mesh vertex that picks the other triangle under contraction) and radiance equal to ~1e-15."""
+    for spec in (scenes.c1_testing(width=33, height=17, spp=1), scenes.c1_testing(width=96, height=54, spp=1),
+                 scenes.c3_blob988(width=96, height=56, spp=4), scenes.c2_spheres(width=80, height=48, spp=4)):
+        res, ref, _ = render_both(spec)
+        assert (res["prim_id"] == ref["prim_id"]).all(), spec.name
+        assert np.abs(res["radiance"] - ref["radiance"]).max() <= 1e-12, spec.name
