@@ -59,7 +59,7 @@
 #define RT_SPECULATE 1      // 1: a lane that reaches a leaf postpones it and keeps traversing until it holds a second one
 #endif
 #ifndef RT_NODE_UNROLL
-#define RT_NODE_UNROLL 4    // node visits per NODE trip (amortises the vote; measured 1: 290 ms, 2: 280, 3: 269, 4: 266 on C4)
+#define RT_NODE_UNROLL 5    // node visits per NODE trip (amortises the vote; with one inline pop: 3: 147.4 ms, 4: 144.3, 5: 142.9, 6: 146.4, 8: 143.9 on C4)
 #endif
 #ifdef RT_ASM_MARKERS
 #define RT_MARK(name) asm volatile("; RTMARK " name ::: "memory")
@@ -68,6 +68,9 @@
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 1024u      // items a wave takes from the global counter at a time (multiple of 64)
+#endif
+#ifndef RT_POPS
+#define RT_POPS 1           // inline predicated pops per step; a lane whose popped entries were all culled continues as CUR_POP
 #endif
 #ifndef RT_PRIM_UNROLL
 #define RT_PRIM_UNROLL 1    // primitive tests per PRIM trip
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 // Branch-free pop for the lanes with p_ set: up to two entries; entries beyond the closest hit are skipped.
 #define RT_POP2(p_)                                                                  \
   do {                                                                               \
-    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) {                               \
+    _Pragma("unroll") for (int a_ = 0; a_ < RT_POPS; ++a_) {                               \
       const int spn_ = sp - 1;                                                       \
       const uint2 e_ = stack[(spn_ < 0 ? 0 : spn_) * 64];                            \
       const bool empty_ = sp == 0;                                                   \
@@ -411,18 +414,19 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         BT tL, tR;
         int refL = 0, refR = 0;
         if constexpr (sizeof(BT) == 4) {
-          float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
-          int2 q3 = make_int2(0, 0);
-          if (isn) {
-            if (cur < fr.top_nodes) {                        // top of the tree: the workgroup's LDS copy (ds_read_b128)
-              const float4 *p = lnodes + 4 * cur;
-              q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
-              asm volatile("" ::: "memory");                 // keep this an LDS load: do not merge with the global path into a FLAT load
-              if (STATS) st[STAT_TOPHIT]++;
-            } else {                                         // scalar base + 32-bit lane offset
-              const char *p = (const char *)nodes + (size_t)((uint32_t)cur << 6);
-              q0 = *(const float4 *)p; q1 = *(const float4 *)(p + 16); q2 = *(const float4 *)(p + 32); q3 = *(const int2 *)(p + 48);
-            }
+          // Lanes that are not at a node read node 0 (always present; a broadcast) instead of being masked off:
+          // no zero-initialised registers, no exec-mask branch around the loads; their results are discarded by `isn`.
+          float4 q0, q1, q2;
+          int2 q3;
+          const int ni = isn ? cur : 0;
+          if (ni < fr.top_nodes) {                           // top of the tree: the workgroup's LDS copy (ds_read_b128)
+            const float4 *p = lnodes + 4 * ni;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
+            asm volatile("" ::: "memory");                   // keep this an LDS load: do not merge with the global path into a FLAT load
+            if (STATS && isn) st[STAT_TOPHIT]++;
+          } else {                                           // scalar base + 32-bit lane offset
+            const char *p = (const char *)nodes + (size_t)((uint32_t)ni << 6);
+            q0 = *(const float4 *)p; q1 = *(const float4 *)(p + 16); q2 = *(const float4 *)(p + 32); q3 = *(const int2 *)(p + 48);
           }
           const float bxL[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
           const float bxR[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
@@ -430,9 +434,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           hR = box_test(br, bxR, tminb, tmaxb, tR) && isn;
           refL = q3.x; refR = q3.y;
         } else {
-          DNode<BT> nd;
-          for (int k = 0; k < 12; ++k) nd.box[k] = 0;
-          if (isn) nd = nodes[cur];
+          const DNode<BT> nd = nodes[isn ? cur : 0];
           hL = box_test(br, nd.box, tminb, tmaxb, tL) && isn;
           hR = box_test(br, nd.box + 6, tminb, tmaxb, tR) && isn;
           refL = nd.ref[0]; refR = nd.ref[1];
@@ -461,11 +463,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
         const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_POP;
         const int pi = ~(use_p ? pend : cur);
-        DPrim P;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) P.d[k] = 0.0;
-        P.mat = 0; P.kind = 0;
-        if (isl) P = *(const DPrim *)((const char *)sc.prims + (size_t)((uint32_t)pi * 80u));
+        // lanes not in a leaf read primitive 0 (always present) and discard the result: see the NODE body
+        const DPrim P = *(const DPrim *)((const char *)sc.prims + (size_t)((uint32_t)(isl ? pi : 0) * 80u));
         const uint32_t kind = P.kind & DPRIM_KIND_MASK;
         // Moller-Trumbore without early exits (Triangle.hs:30-53): same operations, same order, the rejections become one predicate
         double t;
