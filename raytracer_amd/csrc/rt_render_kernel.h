@@ -120,6 +120,22 @@ RT_DEV uint32_t fastdiv24(uint32_t n, uint32_t d, float rcp) {
 // gamma correction c ** gamma (Trace.hs:103-105), out of line: the FP64 pow body must not set the kernel's register budget
 __device__ __attribute__((noinline)) double pow_gamma(double c, double g) { return pow(c, g); }
 
+// The two parameter structs are 720 bytes of kernel arguments.  Held in SGPRs for the whole kernel they overflow the
+// scalar register file (107 SGPRs were spilled into VGPR lanes and read back with v_readlane inside the NODE and PRIM
+// loops).  The cold sections (SHADE, refill) therefore re-read the fields they need from the kernarg segment at the
+// point of use - scalar loads that hit the scalar cache - through a pointer the optimiser cannot see through, and the
+// values die at the end of the section.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RT_NO_COLD_ARGS)   // (the host pass only parses the kernel body)
+#define RT_KARG_AS __attribute__((address_space(4)))
+#define RT_COLD_ARGS()                                                                                    \
+  const RT_KARG_AS char *ka_ = (const RT_KARG_AS char *)__builtin_amdgcn_kernarg_segment_ptr();          \
+  asm volatile("" : "+s"(ka_));                                                                           \
+  const KScene sc = *(const RT_KARG_AS KScene *)ka_;                                                      \
+  const KFrame fr = *(const RT_KARG_AS KFrame *)(ka_ + ((sizeof(KScene) + alignof(KFrame) - 1) / alignof(KFrame)) * alignof(KFrame))
+#else
+#define RT_COLD_ARGS() do { } while (0)
+#endif
+
 template <typename BT, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
   extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: [entry][lane] stack
@@ -128,6 +144,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   uint2 *stack = lds_all + (size_t)fr.top_nodes * 8 + (size_t)(threadIdx.x >> 6) * fr.stack_depth * 64 + lane;
   double *rec = fr.fscratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PR_ROWS * 64 + lane;
   const DNode<BT> *nodes = (const DNode<BT> *)sc.nodes;
+  const int top_nodes_v = fr.top_nodes;
   const double inf = __builtin_huge_val();
   const BT tminb = tmin_for_boxes<BT>();
 
@@ -193,11 +210,12 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   // Gives every idle lane its next item.  All lanes of the wave run this (uniform control flow).
   // item q of this launch -> local tile q / (64 spp), position in the 8x8 tile (q / spp) % 64, sample q % spp.
   // The chunk start is decomposed once per chunk (wave-uniform); a lane's item then needs only small divisions.
-  const uint32_t per_tile = 64u * (uint32_t)fr.spp;
-  const float rcp_spp = 1.0f / (float)fr.spp, rcp_tx = 1.0f / (float)fr.tiles_x;
-  const bool small_div = fr.spp < (1 << 22) && (uint32_t)fr.tiles_x * (uint32_t)((fr.H + 7) / 8) < (1u << 24);
   uint32_t pool_base = 0, pool_lt0 = 0, pool_pos0 = 0, pool_s0 = 0;
   auto refill = [&]() {
+    RT_COLD_ARGS();
+    const uint32_t per_tile = 64u * (uint32_t)fr.spp;
+    const float rcp_spp = 1.0f / (float)fr.spp, rcp_tx = 1.0f / (float)fr.tiles_x;
+    const bool small_div = fr.spp < (1 << 22) && (uint32_t)fr.tiles_x * (uint32_t)((fr.H + 7) / 8) < (1u << 24);
     for (;;) {
       const unsigned long long need = __ballot(cur == CUR_IDLE);
       if (need == 0ull) break;
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (STATS) st[STAT_IT_SHADE]++;
       RT_TICK(0);
       RT_MARK("SHADE_BEGIN");
-      if (is_done) {
+      if (is_done) {                                         // (every sub-block re-reads the arguments it needs: RT_COLD_ARGS)
         double *r = rec;
         asm volatile("" : "+v"(r) : : "memory");            // the record is re-read from memory, never carried in registers
         const bool anyhit = li >= 0;
@@ -288,6 +306,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (best < 0) {                                    // Trace.hs:25: background along the current ray
             need_finish = true;
           } else {
+            RT_COLD_ARGS();
             const int2 sb = rec_ldi(r, PR_SB);
             if (sb.x == 0 && sb.y == 0 && fr.out_primid)   // primary hit of sample 0: the pixel's id (slot of a packed output: tile*64 + position)
               fr.out_primid[fr.packed ? (uint32_t)fr.tile_begin * 64u + item / (uint32_t)fr.spp : pixel] = sc.prim_ids[best];
@@ -309,6 +328,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           }
         } else {
           if (best < 0) {                                    // unblocked: Light.hs:36-38 / :48-49
+            RT_COLD_ARGS();
             const DLight L = sc.lights[li];
             const d3 lnormal = normalize3(rec_ld(r, PR_NRM));   // Light.hs:19
             const double lightPower = fmax(0.0, dot3(lnormal, rd));
@@ -328,6 +348,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (li < 0) need_scatter = true;
         }
         if (!need_scatter && !need_finish) {                 // shadow ray towards light li (Light.hs:26-30, 39-42)
+          RT_COLD_ARGS();
           const DLight L = sc.lights[li];
           if (L.kind == RT_LIGHT_POINT) {
             const d3 tl = ld3(L.vec) - ro;
@@ -339,6 +360,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           }
         }
         if (need_scatter) {                                  // Trace.hs:27-76
+          RT_COLD_ARGS();
           const int2 mf = rec_ldi(r, PR_MF);
           const int2 sb = rec_ldi(r, PR_SB);
           const DMaterial M = sc.mats[mf.x];
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (sb.y + 1 >= fr.maxb) { need_ray0 = true; need_finish = true; }     // depth 0: background along ray0, :22
         }
         if (need_finish) {                                   // path end: its radiance goes to the per-sample buffer
+          RT_COLD_ARGS();
           if (need_ray0) {                                   // depth ran out: background along the PRIMARY ray (Trace.hs:22), regenerated
             d3 o_;
             camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)rec_ldi(r, PR_SB).x, o_, bgdir);
@@ -390,7 +413,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
           cur = CUR_IDLE;                                    // the lane is free: it pulls its next item in the refill below
         }
-        if (cur != CUR_IDLE) RT_BEGIN_QUERY(q_tmax);
+        if (cur != CUR_IDLE) { RT_COLD_ARGS(); RT_BEGIN_QUERY(q_tmax); }
       }
       RT_MARK("SHADE_END");
       RT_TICK(3);
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           float4 q0, q1, q2;
           int2 q3;
           const int ni = isn ? cur : 0;
-          if (ni < fr.top_nodes) {                           // top of the tree: the workgroup's LDS copy (ds_read_b128)
+          if (ni < top_nodes_v) {                            // top of the tree: the workgroup's LDS copy (ds_read_b128)
             const float4 *p = lnodes + 4 * ni;
             q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
             asm volatile("" ::: "memory");                   // keep this an LDS load: do not merge with the global path into a FLAT load
