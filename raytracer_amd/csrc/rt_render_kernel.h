@@ -1,56 +1,37 @@
-// rt_render_kernel.h — the render kernel as a VOTE-SCHEDULED per-lane state machine, cold path state out of
-// the register file (v3), and LANES AS WORKERS that pull pixels from a pool (v4).
+// rt_render_kernel.h — k_render_tiles: the reference's whole per-path loop nest (RenderWorker.hs:53-114,
+// Trace.hs:19-105, Light.hs:16-49, BVH.hs:120-146) as ONE persistent wave64 kernel.  Design notes, measurements
+// and the history of the numbers quoted here: DESIGN.md sections 5 and 7.
 //
-// v1 ran one complete BVH query per lane per outer trip, so every lane waited for the longest
-// traversal of its wave (measured VALU lane utilisation 22 %, profiles/r01_summary.md).  Since v2
-// every lane carries its traversal state across trips and each trip of the wave executes exactly ONE
-// of three bodies, picked by wave-uniform ballots:
-//     NODE  step : lanes at an internal node fetch it, test both child boxes, descend / push / pop
-//     PRIM  step : lanes in a leaf test one primitive and advance / pop
-//     SHADE step : lanes whose query finished run the path state transition (light loop, material
-//                  bounce, path end, next sample) and start their next query
-// so a finished lane never idles until the slowest ray of the wave is done.
+// Work items.  A lane is a worker that pulls PATHS: item q <-> (tile of this rank's list, position in the 8x8
+// tile, sample).  A wave takes RT_CHUNK consecutive items at a time from one global atomic counter and hands them to
+// its lanes as they fall idle (refill); consecutive items are consecutive samples of one pixel, so a freshly filled
+// wave traces 64 nearly identical primary rays.  The RNG is keyed by (pixel, sample); the path's radiance goes to
+// samples[q] and k_resolve sums each pixel's samples in sample order (RenderWorker.hs:111-114), so a frame does not
+// depend on which lane, wave, launch or GPU traced a path.
 //
-// v3: only the TRAVERSAL state (ray, closest hit, stack pointer, box-space ray: ~40 registers) is live
-// during NODE/PRIM steps.  The path state that only SHADE needs — incoming direction, normal,
-// attenuation, the pending clamp function F(x) = clamp(x + a, L, H), sample/bounce counters — is a
-// per-lane RECORD in a global scratch row ([wave][row][lane], coalesced 512-B rows, L2-resident); SHADE
-// loads the fields it needs and stores the ones it changes.  The pixel's running sum lives in LDS.
-// That takes the kernel from 256 VGPRs (2 waves/SIMD) towards 4 waves/SIMD.
+// Vote-scheduled state machine.  Every lane carries its traversal state across trips of the main loop; each trip
+// executes exactly ONE of three bodies, picked by wave-uniform ballots, so a finished lane never waits for the
+// slowest ray of its wave:
+//     NODE  : lanes at an internal node fetch it (LDS copy of the top levels, else global), test both child boxes,
+//             descend into the nearer child, push the other one, or pop           (RT_NODE_UNROLL visits per trip)
+//     PRIM  : lanes in a leaf test one primitive (FP64, the reference's operations in its order) and advance / pop
+//     SHADE : lanes whose query finished run the path transition (hit -> emission, shadow rays light by light,
+//             material bounce; miss / depth out -> background, store the sample) and start their next query
+// NODE and PRIM are straight-line predicated code: selects instead of nested ifs, no early exits in the triangle
+// test, lanes in another state read element 0 and discard the result instead of being masked off, one inline pop
+// per step (a lane whose popped entry was culled continues as CUR_POP), spheres / planes behind a wave-uniform branch.
+//
+// Registers.  Only the traversal state (ray, box-space ray, closest hit, stack pointer: ~40 VGPRs) is live in
+// NODE / PRIM.  What only SHADE needs - incoming direction, normal, attenuation, the pending clamp function
+// F(x) = clamp(x + a, L, H), sample / bounce counters - is a per-lane RECORD in global memory ([wave][row][lane],
+// coalesced 512-B rows), re-read by SHADE; libm bodies (pow, atan2/asin) are kept out of line; SHADE and refill re-read
+// their kernel arguments from the kernarg segment (RT_COLD_ARGS).  128 VGPRs: 16 waves per CU in one workgroup.
+// The per-lane traversal stack (ref, entry distance) is in LDS, [wave][entry][lane].
+//
+// State of a lane, in ONE register: cur >= 0 internal node index, CUR_IDLE no item, CUR_DONE query finished (waits
+// for SHADE), CUR_POP owes a pop, anything else negative = leaf reference ~first_primitive.
 // Numerics: emission and each light's term are added to `a` as they arrive, i.e. the reference's
-// `e + surf*(l1 + (l2 + ...)) + clamp(..)` is summed in a different order (~1e-16 relative).
-//
-// v4: in v3 a wave owned one 8x8 tile until its slowest pixel was done; on the metric scene only 48 of 64
-// lanes still had work on an average trip.  Now a lane that finishes its pixel (all spp samples, summed in
-// order) writes it out and immediately takes the next pixel slot from a wave-local pool, which the wave
-// refills one tile (64 slots, tile order) at a time from the global atomic counter.  A wave therefore stays
-// full until the frame runs dry; pixels of at most a few consecutive tiles share a wave (coherence kept).
-// Results are unchanged: a pixel is still computed by ONE lane, sample by sample, RNG keyed by the pixel.
-//
-// v5: LDS-cached top of the BVH.  rocprofv3 shows v3/v4 bound by the vector L1 (TCP active 88 %, TD busy 77 %,
-// ~113 scattered cache-line accesses per ray, profiles/): every lane's node fetch is 4 x 16 B from its own line.
-// The internal nodes are stored top levels first (breadth-first), so the first `top_nodes` of them — the ones
-// every ray walks through — are copied into LDS once per workgroup; ONE workgroup of RT_BLOCK_THREADS threads
-// per CU shares that copy, and a NODE step reads cached nodes with ds_read_b128 instead of going through the TCP.
-//
-// v6: the lane state lives in ONE register: cur >= 0 internal node, CUR_IDLE no pixel, CUR_DONE query finished
-// (waiting for SHADE), anything else negative = leaf reference; cached nodes are read with explicit LDS loads
-// (v5's pointer select made the compiler emit FLAT loads, which still occupy the vector-memory path), global
-// nodes/primitives are addressed with 32-bit offsets from a scalar base, and the NODE body is branch-light.
-//
-// v7: the occupancy sweep shows the SIMDs instruction-issue bound, with ~45 % of the
-// issued instructions being SALU/branch overhead of divergent control flow.  The NODE and PRIM bodies are
-// therefore STRAIGHT-LINE predicated code: selects instead of nested ifs, no early exits in the triangle test,
-// two inline predicated pops (a lane whose two popped entries were both culled continues in state CUR_POP),
-// spheres/planes behind a wave-uniform branch that all-triangle leaves never take.
-//
-// v8: the work item is ONE PATH (pixel, sample), not a pixel.  A lane used to own a pixel for all its spp samples
-// (25 ms of work on the metric scene), so the end of a frame - or of one GPU's share of it when the frame is cut
-// over 8 GPUs - drained for one pixel-time with half the lanes idle.  Now lanes pull items `q = (tile, position in
-// tile, sample)` from the wave's pool; consecutive items are consecutive samples of one pixel, so a freshly filled
-// wave traces 64 nearly identical primary rays.  Each path writes its radiance to samples[q] (24 B; 5 GB for
-// 1080p x 100 spp - HBM has 288 GB) and k_resolve sums a pixel's samples IN SAMPLE ORDER (the reference's foldl',
-// RenderWorker.hs:111-114), so the frame is bit-identical to the pixel-per-lane version and to any sharding.
+// `e + surf*(l1 + (l2 + ...)) + clamp(..)` is summed in a different order (<= 1 ulp, only with several lights).
 #pragma once
 #define CUR_IDLE ((int)0x80000000)
 #define CUR_DONE ((int)0x80000001)
