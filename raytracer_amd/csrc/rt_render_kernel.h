@@ -300,9 +300,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             else outward = mk3(P.d[3], P.d[4], P.d[5]);                                                                            // Plane.hs:29
             const bool front = dot3(rd, outward) < 0;        // Class.hs:24
             rec_st(r, PR_NRM, front ? outward : neg3(outward));   // :25
-            rec_st(r, PR_UDIR, normalize3(rd));              // Trace.hs:32
+            const DMaterial &Mh = sc.mats[P.mat];
+            if (Mh.flags & (DMAT_GLASS_DIR | DMAT_METAL))   // unitDir (Trace.hs:32) is only used by the glass and metal bounces
+              rec_st(r, PR_UDIR, normalize3(rd));
             rec_sti(r, PR_MF, P.mat, front ? 1 : 0);
-            rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(sc.mats[P.mat].emission));   // emitted (Trace.hs:29) joins the pending offset
+            rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(Mh.emission));   // emitted (Trace.hs:29) joins the pending offset
             ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
             if (STATS) st[STAT_SHADED]++;
             if (sc.n_lights > 0) li = sc.n_lights - 1; else need_scatter = true;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           const int2 sb = rec_ldi(r, PR_SB);
           const DMaterial M = sc.mats[mf.x];
           const bool front = mf.y != 0;
-          const d3 udir = rec_ld(r, PR_UDIR), nrm = rec_ld(r, PR_NRM);
+          const d3 nrm = rec_ld(r, PR_NRM);
           // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
           //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)
           {
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           const d3 randVec = normalize3(mk3(um11(w.x), um11(w.y), um11(w.z)));   // :38-42
           const double randD = u01(w.w);                                         // :41
           if (M.flags & DMAT_GLASS_DIR) {                                        // :48-59
+            const d3 udir = rec_ld(r, PR_UDIR);
             const double eta = front ? 1.0 / M.ior : M.ior;
             const double cosTheta = fmin(-dot3(udir, nrm), 1.0);
             const double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             if (eta * sinTheta > 1.0 || randD < reflectProb) rd = reflect3(udir, nrm);
             else rd = refract3(udir, nrm, eta);
           } else if (M.flags & DMAT_METAL) {                                     // :60-64
-            rd = normalize3(reflect3(udir, nrm) + 0.05 * randVec);
+            rd = normalize3(reflect3(rec_ld(r, PR_UDIR), nrm) + 0.05 * randVec);
           } else {                                                               // :65-67
             rd = normalize3(nrm + randVec);
           }
