@@ -21,6 +21,7 @@ struct KScene {
   const DMaterial *mats;
   const DLight *lights;
   const double *plane_boxes;   // 6 doubles per plane: the FP64 box of the leaf holding it
+  const double *tri_normals;   // 6 doubles per primitive (triangles only): n = normalize(e1 x e2) (Triangle.hs:51) and normalize(n) (Light.hs:19)
   const void *sky;
   int32_t root_ref;
   int32_t n_lights;

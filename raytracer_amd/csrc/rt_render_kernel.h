@@ -80,7 +80,10 @@
 #ifndef RT_REC_ROWS_DEFINED
 #define RT_REC_ROWS_DEFINED
 enum { PR_UDIR = 0, PR_NRM = 3, PR_ATT = 6, PR_FA = 9, PR_FL = 12, PR_FH = 15, PR_SB = 18 /* int2: sample, bounce */,
-       PR_MF = 19 /* int2: material index, front face */, PR_ROWS = 20 };
+       PR_MF = 19 /* int2: material index | flags, primitive */, PR_ROWS = 20 };
+#define PR_MF_FRONT 0x40000000
+#define PR_MF_TRI   ((int)0x80000000)
+#define PR_MF_MAT   0x3fffffff
 
 RT_DEV d3 rec_ld(const double *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
 RT_DEV void rec_st(double *r, int row, d3 v) { r[row * 64] = v.x; r[(row + 1) * 64] = v.y; r[(row + 2) * 64] = v.z; }
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             const uint32_t kind = P.kind & DPRIM_KIND_MASK;
             const d3 hp = ro + best_t * rd;                  // R.at ray t
             d3 outward;
-            if (kind == RT_PRIM_TRIANGLE) outward = normalize3(cross3(mk3(P.d[3], P.d[4], P.d[5]), mk3(P.d[6], P.d[7], P.d[8])));   // Triangle.hs:51
+            if (kind == RT_PRIM_TRIANGLE) outward = ld3(sc.tri_normals + 6 * (size_t)best);   // normalize(e1 x e2), Triangle.hs:51, precomputed at upload
             else if (kind == RT_PRIM_SPHERE) outward = (1.0 / P.d[3]) * (hp - mk3(P.d[0], P.d[1], P.d[2]));                        // Sphere.hs:38
             else outward = mk3(P.d[3], P.d[4], P.d[5]);                                                                            // Plane.hs:29
             const bool front = dot3(rd, outward) < 0;        // Class.hs:24
@@ -303,7 +306,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             const DMaterial &Mh = sc.mats[P.mat];
             if (Mh.flags & (DMAT_GLASS_DIR | DMAT_METAL))   // unitDir (Trace.hs:32) is only used by the glass and metal bounces
               rec_st(r, PR_UDIR, normalize3(rd));
-            rec_sti(r, PR_MF, P.mat, front ? 1 : 0);
+            // material index | front-face bit | triangle bit, and the primitive (its precomputed lighting normal)
+            rec_sti(r, PR_MF, P.mat | (front ? PR_MF_FRONT : 0) | (kind == RT_PRIM_TRIANGLE ? PR_MF_TRI : 0), best);
             rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(Mh.emission));   // emitted (Trace.hs:29) joins the pending offset
             ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
             if (STATS) st[STAT_SHADED]++;
@@ -313,7 +317,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (best < 0) {                                    // unblocked: Light.hs:36-38 / :48-49
             RT_COLD_ARGS();
             const DLight L = sc.lights[li];
-            const d3 lnormal = normalize3(rec_ld(r, PR_NRM));   // Light.hs:19
+            const int2 mfl = rec_ldi(r, PR_MF);
+            d3 lnormal;                                      // normalize (hitNormal hit), Light.hs:19
+            if (mfl.x & PR_MF_TRI) {                         // triangles: precomputed; normalize(-n) == -normalize(n) exactly
+              const d3 n2 = ld3(sc.tri_normals + 6 * (size_t)mfl.y + 3);
+              lnormal = (mfl.x & PR_MF_FRONT) ? n2 : neg3(n2);
+            } else {
+              lnormal = normalize3(rec_ld(r, PR_NRM));
+            }
             const double lightPower = fmax(0.0, dot3(lnormal, rd));
             d3 contrib;
             if (L.kind == RT_LIGHT_POINT) {
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             } else {
               contrib = lightPower * ld3(L.intensity);
             }
-            const int mi = rec_ldi(r, PR_MF).x;              // litColor = surfaceColor * directLight (Trace.hs:36), light by light
+            const int mi = mfl.x & PR_MF_MAT;                // litColor = surfaceColor * directLight (Trace.hs:36), light by light
             rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(sc.mats[mi].diffuse) * contrib);
           }
           --li;
@@ -346,8 +357,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           RT_COLD_ARGS();
           const int2 mf = rec_ldi(r, PR_MF);
           const int2 sb = rec_ldi(r, PR_SB);
-          const DMaterial M = sc.mats[mf.x];
-          const bool front = mf.y != 0;
+          const DMaterial M = sc.mats[mf.x & PR_MF_MAT];
+          const bool front = (mf.x & PR_MF_FRONT) != 0;
           const d3 nrm = rec_ld(r, PR_NRM);
           // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
           //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)

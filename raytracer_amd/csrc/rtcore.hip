@@ -74,6 +74,7 @@ struct rt_scene {
   DMaterial *d_mats = nullptr;
   DLight *d_lights = nullptr;
   double *d_plane_boxes = nullptr;
+  double *d_tri_normals = nullptr;
   void *d_sky = nullptr;
   std::vector<DNode<double>> h_nodes64;
   KScene ks{};
@@ -126,7 +127,7 @@ void rt_shutdown(void) { g_ctx.ready = false; }
 void rt_scene_destroy(rt_scene *s) {
   if (!s) return;
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
-  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_sky);
+  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky);
   (void)hipFree(s->d_counter); (void)hipFree(s->d_stats); (void)hipFree(s->d_fscratch); (void)hipFree(s->d_samples);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_tiles);
   for (hipEvent_t e : s->kt_events) (void)hipEventDestroy(e);
@@ -232,6 +233,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   std::vector<DPrim> prims(np);
   std::vector<int32_t> pids(np);
   std::vector<double> plane_boxes;
+  // Per triangle: the face normal the reference recomputes at every hit, normalize(e1 x e2) (Triangle.hs:51), and the
+  // re-normalisation computeLighting applies to it (Light.hs:19).  Same operations in the same order as the device
+  // helpers cross3 / dot3 / normalize3 (rt_device.h), IEEE sqrt and division, no contraction: bit-identical values.
+  std::vector<double> tri_normals((size_t)np * 6, 0.0);
+  auto normalize_like_device = [](const double v[3], double out[3]) {
+    const double s = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    out[0] = s * v[0]; out[1] = s * v[1]; out[2] = s * v[2];
+  };
   double maxabs = 0;
   for (int i = 0; i < np; ++i) {
     const double *src = d->prim_data + 9 * (size_t)i;
@@ -245,6 +254,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         P.d[3 + k] = src[3 + k] - src[k];   // e1 = p1 - p0, Triangle.hs:32
         P.d[6 + k] = src[6 + k] - src[k];   // e2 = p2 - p0, Triangle.hs:33
       }
+      const double *a = P.d + 3, *b = P.d + 6;
+      const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+      normalize_like_device(c, &tri_normals[6 * (size_t)i]);
+      normalize_like_device(&tri_normals[6 * (size_t)i], &tri_normals[6 * (size_t)i + 3]);
     } else {
       for (int k = 0; k < 9; ++k) P.d[k] = src[k];
       if (kind == RT_PRIM_PLANE) P.d[6] = -1.0;
@@ -310,6 +323,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   UP(dev_upload(&s->d_mats, mats.data(), mats.size()));
   UP(dev_upload(&s->d_lights, lights.data(), lights.size()));
   UP(dev_upload(&s->d_plane_boxes, plane_boxes.data(), plane_boxes.size()));
+  UP(dev_upload(&s->d_tri_normals, tri_normals.data(), tri_normals.size()));
   if (d->sky_format != RT_SKY_NONE) {
     size_t bytes = (size_t)d->sky_width * d->sky_height * 3 * (d->sky_format == RT_SKY_RGB8 ? 1 : 4);
     uint8_t *p = nullptr;
@@ -325,7 +339,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
 
   KScene &k = s->ks;
   k.nodes = s->d_nodes32; k.prims = s->d_prims; k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
-  k.plane_boxes = s->d_plane_boxes; k.sky = s->d_sky;
+  k.plane_boxes = s->d_plane_boxes; k.tri_normals = s->d_tri_normals; k.sky = s->d_sky;
   k.root_ref = is_leaf(0) ? d->node_child[0] : 0;
   k.n_lights = d->n_lights;
   k.bg_kind = d->bg_kind; k.sky_format = d->sky_format; k.sky_w = d->sky_width; k.sky_h = d->sky_height;
