@@ -282,33 +282,55 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         double *r = rec;
         asm volatile("" : "+v"(r) : : "memory");            // the record is re-read from memory, never carried in registers
         const bool anyhit = li >= 0;
+        const bool is_h = !anyhit && best >= 0;              // closest-hit query found a surface
         bool need_scatter = false, need_finish = false;
         double q_tmax = RT_TMAX;
         bool need_ray0 = false;                              // background along the PRIMARY ray (depth exhausted, Trace.hs:22)
         d3 bgdir = rd;
+        // ---- All memory this trip can need is requested up front, in two rounds of independent loads, instead of one
+        // dependent round trip per use: SHADE is latency bound (records and scene compete for 4 MB of L2 per XCD).
+        // Round 1: the whole record and the header of the hit primitive.
+        int2 sb = rec_ldi(r, PR_SB);
+        int2 mf = rec_ldi(r, PR_MF);                         // (valid once the path has had a hit)
+        d3 fa = rec_ld(r, PR_FA), att = rec_ld(r, PR_ATT), nrm = rec_ld(r, PR_NRM);
+        d3 fl = rec_ld(r, PR_FL), fh = rec_ld(r, PR_FH);
+        int2 pkm;                                            // (material, kind) of the hit primitive
+        d3 tn;                                               // triangles: face normal (hit section) / lighting normal (light section)
+        DMaterial M;
+        {
+          RT_COLD_ARGS();
+          pkm = *(const int2 *)((const char *)sc.prims + (size_t)(uint32_t)(is_h ? best : 0) * 80u + 72u);
+          // Round 2: normal and material, addressed by the primitive just hit or by the one the record remembers.
+          const int pidx = is_h ? best : (anyhit ? mf.y : 0);
+          tn = ld3(sc.tri_normals + 6 * (size_t)pidx + (is_h ? 0 : 3));
+          M = sc.mats[is_h ? pkm.x : (anyhit ? (mf.x & PR_MF_MAT) : 0)];
+        }
         if (!anyhit) {
           if (best < 0) {                                    // Trace.hs:25: background along the current ray
             need_finish = true;
           } else {
             RT_COLD_ARGS();
-            const int2 sb = rec_ldi(r, PR_SB);
             if (sb.x == 0 && sb.y == 0 && fr.out_primid)   // primary hit of sample 0: the pixel's id (slot of a packed output: tile*64 + position)
               fr.out_primid[fr.packed ? (uint32_t)fr.tile_begin * 64u + item / (uint32_t)fr.spp : pixel] = sc.prim_ids[best];
-            const DPrim P = sc.prims[best];
-            const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+            const uint32_t kind = (uint32_t)pkm.y & DPRIM_KIND_MASK;
             const d3 hp = ro + best_t * rd;                  // R.at ray t
             d3 outward;
-            if (kind == RT_PRIM_TRIANGLE) outward = ld3(sc.tri_normals + 6 * (size_t)best);   // normalize(e1 x e2), Triangle.hs:51, precomputed at upload
-            else if (kind == RT_PRIM_SPHERE) outward = (1.0 / P.d[3]) * (hp - mk3(P.d[0], P.d[1], P.d[2]));                        // Sphere.hs:38
-            else outward = mk3(P.d[3], P.d[4], P.d[5]);                                                                            // Plane.hs:29
+            if (kind == RT_PRIM_TRIANGLE) outward = tn;      // normalize(e1 x e2), Triangle.hs:51, precomputed at upload
+            else {
+              const DPrim P = sc.prims[best];
+              if (kind == RT_PRIM_SPHERE) outward = (1.0 / P.d[3]) * (hp - mk3(P.d[0], P.d[1], P.d[2]));   // Sphere.hs:38
+              else outward = mk3(P.d[3], P.d[4], P.d[5]);                                                   // Plane.hs:29
+            }
             const bool front = dot3(rd, outward) < 0;        // Class.hs:24
-            rec_st(r, PR_NRM, front ? outward : neg3(outward));   // :25
-            const DMaterial &Mh = sc.mats[P.mat];
-            if (Mh.flags & (DMAT_GLASS_DIR | DMAT_METAL))   // unitDir (Trace.hs:32) is only used by the glass and metal bounces
+            nrm = front ? outward : neg3(outward);           // :25
+            rec_st(r, PR_NRM, nrm);
+            if (M.flags & (DMAT_GLASS_DIR | DMAT_METAL))    // unitDir (Trace.hs:32) is only used by the glass and metal bounces
               rec_st(r, PR_UDIR, normalize3(rd));
             // material index | front-face bit | triangle bit, and the primitive (its precomputed lighting normal)
-            rec_sti(r, PR_MF, P.mat | (front ? PR_MF_FRONT : 0) | (kind == RT_PRIM_TRIANGLE ? PR_MF_TRI : 0), best);
-            rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(Mh.emission));   // emitted (Trace.hs:29) joins the pending offset
+            mf = make_int2(pkm.x | (front ? PR_MF_FRONT : 0) | (kind == RT_PRIM_TRIANGLE ? PR_MF_TRI : 0), best);
+            rec_sti(r, PR_MF, mf.x, mf.y);
+            fa = fa + ld3(M.emission);                       // emitted (Trace.hs:29) joins the pending offset
+            rec_st(r, PR_FA, fa);
             ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
             if (STATS) st[STAT_SHADED]++;
             if (sc.n_lights > 0) li = sc.n_lights - 1; else need_scatter = true;
@@ -317,14 +339,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (best < 0) {                                    // unblocked: Light.hs:36-38 / :48-49
             RT_COLD_ARGS();
             const DLight L = sc.lights[li];
-            const int2 mfl = rec_ldi(r, PR_MF);
             d3 lnormal;                                      // normalize (hitNormal hit), Light.hs:19
-            if (mfl.x & PR_MF_TRI) {                         // triangles: precomputed; normalize(-n) == -normalize(n) exactly
-              const d3 n2 = ld3(sc.tri_normals + 6 * (size_t)mfl.y + 3);
-              lnormal = (mfl.x & PR_MF_FRONT) ? n2 : neg3(n2);
-            } else {
-              lnormal = normalize3(rec_ld(r, PR_NRM));
-            }
+            if (mf.x & PR_MF_TRI) lnormal = (mf.x & PR_MF_FRONT) ? tn : neg3(tn);   // precomputed; normalize(-n) == -normalize(n) exactly
+            else lnormal = normalize3(nrm);
             const double lightPower = fmax(0.0, dot3(lnormal, rd));
             d3 contrib;
             if (L.kind == RT_LIGHT_POINT) {
@@ -335,8 +352,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             } else {
               contrib = lightPower * ld3(L.intensity);
             }
-            const int mi = mfl.x & PR_MF_MAT;                // litColor = surfaceColor * directLight (Trace.hs:36), light by light
-            rec_st(r, PR_FA, rec_ld(r, PR_FA) + ld3(sc.mats[mi].diffuse) * contrib);
+            fa = fa + ld3(M.diffuse) * contrib;              // litColor = surfaceColor * directLight (Trace.hs:36), light by light
+            rec_st(r, PR_FA, fa);
           }
           --li;
           if (li < 0) need_scatter = true;
@@ -355,17 +372,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         }
         if (need_scatter) {                                  // Trace.hs:27-76
           RT_COLD_ARGS();
-          const int2 mf = rec_ldi(r, PR_MF);
-          const int2 sb = rec_ldi(r, PR_SB);
-          const DMaterial M = sc.mats[mf.x & PR_MF_MAT];
           const bool front = (mf.x & PR_MF_FRONT) != 0;
-          const d3 nrm = rec_ld(r, PR_NRM);
           // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
           //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)
           {
-            const d3 Fa = rec_ld(r, PR_FA), FL = rec_ld(r, PR_FL), FH = rec_ld(r, PR_FH);
-            rec_st(r, PR_FL, clamp3(Fa, FL, FH));
-            rec_st(r, PR_FH, clamp3(mk3(Fa.x + 10.0, Fa.y + 10.0, Fa.z + 10.0), FL, FH));
+            const d3 nl = clamp3(fa, fl, fh), nh = clamp3(mk3(fa.x + 10.0, fa.y + 10.0, fa.z + 10.0), fl, fh);
+            fl = nl; fh = nh;
+            rec_st(r, PR_FL, fl);
+            rec_st(r, PR_FH, fh);
           }
           const u4 w = philox4x32_10(pixel, (uint32_t)sb.x, 1u + (uint32_t)sb.y, 0u, fr.key0, fr.key1);
           const d3 randVec = normalize3(mk3(um11(w.x), um11(w.y), um11(w.z)));   // :38-42
@@ -390,20 +404,20 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           } else {                                                               // :65-67
             rd = normalize3(nrm + randVec);
           }
-          d3 atten = rec_ld(r, PR_ATT);
-          if (!(M.flags & DMAT_NO_ATTEN)) { atten = atten * ld3(M.diffuse); rec_st(r, PR_ATT, atten); }   // :69-72
-          rec_sti(r, PR_SB, sb.x, sb.y + 1);
+          if (!(M.flags & DMAT_NO_ATTEN)) { att = att * ld3(M.diffuse); rec_st(r, PR_ATT, att); }   // :69-72
+          sb.y += 1;
+          rec_sti(r, PR_SB, sb.x, sb.y);
           li = -1;
-          if (sb.y + 1 >= fr.maxb) { need_ray0 = true; need_finish = true; }     // depth 0: background along ray0, :22
+          if (sb.y >= fr.maxb) { need_ray0 = true; need_finish = true; }         // depth 0: background along ray0, :22
         }
         if (need_finish) {                                   // path end: its radiance goes to the per-sample buffer
           RT_COLD_ARGS();
           if (need_ray0) {                                   // depth ran out: background along the PRIMARY ray (Trace.hs:22), regenerated
             d3 o_;
-            camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)rec_ldi(r, PR_SB).x, o_, bgdir);
+            camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)sb.x, o_, bgdir);
           }
-          const d3 T = rec_ld(r, PR_ATT) * background(sc, bgdir);
-          const d3 R = clamp3(T + rec_ld(r, PR_FA), rec_ld(r, PR_FL), rec_ld(r, PR_FH));
+          const d3 T = att * background(sc, bgdir);
+          const d3 R = clamp3(T + fa, fl, fh);
           double *o_ = fr.samples + 3 * (size_t)item;
           o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
           cur = CUR_IDLE;                                    // the lane is free: it pulls its next item in the refill below
