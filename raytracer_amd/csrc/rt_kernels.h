@@ -53,13 +53,9 @@ struct KFrame {
 
 enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
 
-// cold code (once per path, not per traversal step) is kept out of line so that its temporaries do not
-// inflate the register allocation of the hot step bodies
-#ifndef RT_OUTLINE_COLD
+// cold code (once per path, not per traversal step).  Inlined: taking KScene/KFrame by reference out of line cost more
+// scratch than it saved registers; only the libm-heavy leaves (sky_uv, pow_gamma) are real calls.
 #define RT_COLD __device__ __forceinline__
-#else
-#define RT_COLD __device__ __attribute__((noinline))
-#endif
 
 #define RT_TMIN 0.001
 #define RT_TMAX 10000.0
@@ -103,7 +99,6 @@ __device__ __attribute__((noinline)) double2 sky_uv(double nx, double ny, double
 
 // ---------------------------------------------------------------- background (Trace.hs:78-83)
 RT_COLD d3 background(const KScene &sc, d3 dir) {
-#ifndef RT_X_NO_SKY
   if (sc.sky_format != RT_SKY_NONE) {                               // SkySphere.hs:32-47
     d3 n = normalize3(dir);
     const double2 uv = sky_uv(n.x, n.y, n.z);
@@ -119,7 +114,6 @@ RT_COLD d3 background(const KScene &sc, d3 dir) {
     const float *p = (const float *)sc.sky;
     return mk3((double)p[k], (double)p[k + 1], (double)p[k + 2]);
   }
-#endif
   if (sc.bg_kind == RT_BG_SOLID) return ld3(sc.bg1);                // ImageGenerator.hs:131
   d3 unit = normalize3(dir);                                        // :133
   double t = 0.5 * (unit.y + 1.0);                                  // :134

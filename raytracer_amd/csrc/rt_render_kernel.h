@@ -167,16 +167,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
     best = -1; sp = 0; cur = sc.root_ref; pend = 0;                                \
     if (STATS) st[li >= 0 ? STAT_SHADOW : STAT_CLOSEST]++;                         \
   } while (0)
-#define RT_POP()                                                                   \
-  do {                                                                             \
-    for (;;) {                                                                     \
-      if (sp == 0) { cur = CUR_DONE; break; }                                      \
-      --sp;                                                                        \
-      const uint2 e_ = stack[sp * 64];                                             \
-      if (!cull_entry(__uint_as_float(e_.y), tmaxb)) { cur = (int)e_.x; break; }   \
-    }                                                                              \
-  } while (0)
-// Branch-free pop for the lanes with p_ set: up to two entries; entries beyond the closest hit are skipped.
+// Branch-free pop for the lanes with p_ set: RT_POPS entries at most; entries beyond the closest hit are skipped.
 #define RT_POP2(p_)                                                                  \
   do {                                                                               \
     _Pragma("unroll") for (int a_ = 0; a_ < RT_POPS; ++a_) {                               \
@@ -391,12 +382,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             const double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
             const double r0 = (1 - eta) / (1 + eta);                             // schlick, :85-89
             const double r0sq = r0 * r0;
-#ifdef RT_SCHLICK_POW
-            const double reflectProb = r0sq + (1 - r0sq) * pow(1 - cosTheta, 5.0);
-#else
             const double omc = 1 - cosTheta;                                     // (1-cos)**5 by multiplication: <= 1 ulp from pow()
             const double reflectProb = r0sq + (1 - r0sq) * (omc * omc * omc * omc * omc);
-#endif
             if (eta * sinTheta > 1.0 || randD < reflectProb) rd = reflect3(udir, nrm);
             else rd = refract3(udir, nrm, eta);
           } else if (M.flags & DMAT_METAL) {                                     // :60-64
@@ -516,9 +503,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         if (STATS && isl && kind == RT_PRIM_TRIANGLE) st[STAT_TRI]++;
         if (__ballot(isl && kind != RT_PRIM_TRIANGLE) != 0ull) {   // wave-uniform: leaves with spheres/planes are rare
           if (isl && kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro, rd, RT_TMIN, best_t, t); }
-#ifndef RT_X_NO_PLANE
           else if (isl && kind == RT_PRIM_PLANE) { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro, rd, RT_TMIN, best_t, t); }
-#endif
         }
         h = h && isl;
         best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
@@ -535,7 +520,6 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
     }
   }
 #undef RT_BEGIN_QUERY
-#undef RT_POP
 #undef RT_POP2
 
   if (STATS && lane == 0) {
