@@ -168,9 +168,11 @@ def main():
                          "nodes_per_ray": round(mine[2] / max(1, mine[0] + mine[1]), 2),
                          "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / max(1, mine[0] + mine[1]), 2),
                          "pmc": pmc,
-                         "note": "frac > 1 is expected: the scene (6 MB) is served from LDS/L1/L2, so the algorithmic bytes never "
-                                 "reach HBM; measured HBM-side traffic is `traffic`. The kernel is VALU-issue bound (pmc.valu_busy_frac, "
-                                 "from the committed rocprofv3 passes), see DESIGN.md section 7"},
+                         "scene_bytes": NODE_BYTES * (scene.bvh.n_nodes - scene.bvh.n_leaves) + PRIM_BYTES * scene.bvh.n_prims,
+                         "note": "algorithmic bytes are mostly served on chip (LDS / L1 / L2, Infinity Cache): frac can exceed 1 "
+                                 "when the scene fits the caches; `traffic` is the measured HBM-side volume per launch "
+                                 "(rocprofv3 FETCH_SIZE/WRITE_SIZE, committed under profiles/). The kernel is latency bound, "
+                                 "see DESIGN.md section 7"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_threads)

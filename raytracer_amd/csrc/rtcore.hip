@@ -403,8 +403,8 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   // stacks still fit the CU's LDS.  What is left of 160 KB caches the top BVH levels.
   const size_t stack_bytes = (size_t)fr.stack_depth * 64 * sizeof(uint2);
   int wpb = RT_BLOCK_THREADS / 64;
-  if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env) & ~3));   // experiment knob
-  while (wpb > 4 && (size_t)wpb * stack_bytes > 150 * 1024) wpb -= 4;
+  if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env)));   // experiment knob
+  while (wpb > 4 && (size_t)wpb * stack_bytes > 150 * 1024) --wpb;
   const int threads = wpb * 64;
   const size_t lds_waves = (size_t)wpb * stack_bytes;
   fr.top_nodes = 0;
