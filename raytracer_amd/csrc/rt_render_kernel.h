@@ -283,17 +283,23 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         // Round 1: the whole record and the header of the hit primitive.
         int2 sb = rec_ldi(r, PR_SB);
         int2 mf = rec_ldi(r, PR_MF);                         // (valid once the path has had a hit)
-        d3 fa = rec_ld(r, PR_FA), att = rec_ld(r, PR_ATT), nrm = rec_ld(r, PR_NRM);
+        d3 fa = rec_ld(r, PR_FA), att = rec_ld(r, PR_ATT), nrm = mk3(0, 0, 0);
         d3 fl = rec_ld(r, PR_FL), fh = rec_ld(r, PR_FH);
         int2 pkm;                                            // (material, kind) of the hit primitive
-        d3 tn;                                               // triangles: face normal (hit section) / lighting normal (light section)
+        d3 tn, tn2;                                          // triangles: face normal n (Triangle.hs:51) and normalize(n) (Light.hs:19)
         DMaterial M;
         {
           RT_COLD_ARGS();
           pkm = *(const int2 *)((const char *)sc.prims + (size_t)(uint32_t)(is_h ? best : 0) * 80u + 72u);
           // Round 2: normal and material, addressed by the primitive just hit or by the one the record remembers.
           const int pidx = is_h ? best : (anyhit ? mf.y : 0);
-          tn = ld3(sc.tri_normals + 6 * (size_t)pidx + (is_h ? 0 : 3));
+          tn = ld3(sc.tri_normals + 6 * (size_t)pidx);
+          tn2 = ld3(sc.tri_normals + 6 * (size_t)pidx + 3);
+          // the face-forwarded normal of a triangle hit is not kept in the record: it is +-n of the remembered primitive
+          if (anyhit) {
+            if (mf.x & PR_MF_TRI) nrm = (mf.x & PR_MF_FRONT) ? tn : neg3(tn);
+            else nrm = rec_ld(r, PR_NRM);
+          }
           M = sc.mats[is_h ? pkm.x : (anyhit ? (mf.x & PR_MF_MAT) : 0)];
         }
         if (!anyhit) {
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             }
             const bool front = dot3(rd, outward) < 0;        // Class.hs:24
             nrm = front ? outward : neg3(outward);           // :25
-            rec_st(r, PR_NRM, nrm);
+            if (kind != RT_PRIM_TRIANGLE) rec_st(r, PR_NRM, nrm);
             if (M.flags & (DMAT_GLASS_DIR | DMAT_METAL))    // unitDir (Trace.hs:32) is only used by the glass and metal bounces
               rec_st(r, PR_UDIR, normalize3(rd));
             // material index | front-face bit | triangle bit, and the primitive (its precomputed lighting normal)
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             RT_COLD_ARGS();
             const DLight L = sc.lights[li];
             d3 lnormal;                                      // normalize (hitNormal hit), Light.hs:19
-            if (mf.x & PR_MF_TRI) lnormal = (mf.x & PR_MF_FRONT) ? tn : neg3(tn);   // precomputed; normalize(-n) == -normalize(n) exactly
+            if (mf.x & PR_MF_TRI) lnormal = (mf.x & PR_MF_FRONT) ? tn2 : neg3(tn2);   // precomputed; normalize(-n) == -normalize(n) exactly
             else lnormal = normalize3(nrm);
             const double lightPower = fmax(0.0, dot3(lnormal, rd));
             d3 contrib;
