@@ -80,10 +80,8 @@
 #ifndef RT_REC_ROWS_DEFINED
 #define RT_REC_ROWS_DEFINED
 enum { PR_UDIR = 0, PR_NRM = 3, PR_ATT = 6, PR_FA = 9, PR_FL = 12, PR_FH = 15, PR_SB = 18 /* int2: sample, bounce */,
-       PR_MF = 19 /* int2: material index | flags, primitive */, PR_ROWS = 20 };
-#define PR_MF_FRONT 0x40000000
-#define PR_MF_TRI   ((int)0x80000000)
-#define PR_MF_MAT   0x3fffffff
+       PR_ROWS = 19 };
+#define HITP_FRONT ((int)0x80000000)   // lane register hitp: the primitive of the path's current hit | front-face bit
 
 RT_DEV d3 rec_ld(const double *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
 RT_DEV void rec_st(double *r, int row, d3 v) { r[row * 64] = v.x; r[(row + 1) * 64] = v.y; r[(row + 2) * 64] = v.z; }
@@ -156,6 +154,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   // the reference; nodes visited before the postponed leaf has narrowed the interval are a superset of the reference's.
   constexpr bool SPEC = (RT_SPECULATE != 0) && sizeof(BT) == 4;
   int pend = 0;
+  // the primitive the path last hit (| HITP_FRONT): kept in a register across the shadow queries, so that SHADE can
+  // address its normal and material in the FIRST round of loads instead of after reading them from the record
+  int hitp = 0;
   // ---- wave-uniform pool of items [pool_next, pool_end)
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
@@ -282,7 +283,6 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         // dependent round trip per use: SHADE is latency bound (records and scene compete for 4 MB of L2 per XCD).
         // Round 1: the whole record and the header of the hit primitive.
         int2 sb = rec_ldi(r, PR_SB);
-        int2 mf = rec_ldi(r, PR_MF);                         // (valid once the path has had a hit)
         d3 fa = rec_ld(r, PR_FA), att = rec_ld(r, PR_ATT), nrm = mk3(0, 0, 0);
         d3 fl = rec_ld(r, PR_FL), fh = rec_ld(r, PR_FH);
         int2 pkm;                                            // (material, kind) of the hit primitive
@@ -290,18 +290,19 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         DMaterial M;
         {
           RT_COLD_ARGS();
-          pkm = *(const int2 *)((const char *)sc.prims + (size_t)(uint32_t)(is_h ? best : 0) * 80u + 72u);
-          // Round 2: normal and material, addressed by the primitive just hit or by the one the record remembers.
-          const int pidx = is_h ? best : (anyhit ? mf.y : 0);
-          tn = ld3(sc.tri_normals + 6 * (size_t)pidx);
-          tn2 = ld3(sc.tri_normals + 6 * (size_t)pidx + 3);
-          // the face-forwarded normal of a triangle hit is not kept in the record: it is +-n of the remembered primitive
+          const size_t pidx = (size_t)(uint32_t)(is_h ? best : (anyhit ? (hitp & ~HITP_FRONT) : 0));   // primitive just hit / of the pending hit
+          pkm = *(const int2 *)((const char *)sc.prims + pidx * 80u + 72u);
+          tn = ld3(sc.tri_normals + 6 * pidx);
+          tn2 = ld3(sc.tri_normals + 6 * pidx + 3);
+          // Round 2: the material (a small, cache-resident table); the face-forwarded normal of a triangle hit is
+          // not kept in the record, it is +-n of the remembered primitive.
           if (anyhit) {
-            if (mf.x & PR_MF_TRI) nrm = (mf.x & PR_MF_FRONT) ? tn : neg3(tn);
+            if (((uint32_t)pkm.y & DPRIM_KIND_MASK) == RT_PRIM_TRIANGLE) nrm = (hitp & HITP_FRONT) ? tn : neg3(tn);
             else nrm = rec_ld(r, PR_NRM);
           }
-          M = sc.mats[is_h ? pkm.x : (anyhit ? (mf.x & PR_MF_MAT) : 0)];
+          M = sc.mats[(is_h || anyhit) ? pkm.x : 0];
         }
+        const bool hit_tri = ((uint32_t)pkm.y & DPRIM_KIND_MASK) == RT_PRIM_TRIANGLE;
         if (!anyhit) {
           if (best < 0) {                                    // Trace.hs:25: background along the current ray
             need_finish = true;
@@ -323,9 +324,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             if (kind != RT_PRIM_TRIANGLE) rec_st(r, PR_NRM, nrm);
             if (M.flags & (DMAT_GLASS_DIR | DMAT_METAL))    // unitDir (Trace.hs:32) is only used by the glass and metal bounces
               rec_st(r, PR_UDIR, normalize3(rd));
-            // material index | front-face bit | triangle bit, and the primitive (its precomputed lighting normal)
-            mf = make_int2(pkm.x | (front ? PR_MF_FRONT : 0) | (kind == RT_PRIM_TRIANGLE ? PR_MF_TRI : 0), best);
-            rec_sti(r, PR_MF, mf.x, mf.y);
+            hitp = best | (front ? HITP_FRONT : 0);
             fa = fa + ld3(M.emission);                       // emitted (Trace.hs:29) joins the pending offset
             rec_st(r, PR_FA, fa);
             ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             RT_COLD_ARGS();
             const DLight L = sc.lights[li];
             d3 lnormal;                                      // normalize (hitNormal hit), Light.hs:19
-            if (mf.x & PR_MF_TRI) lnormal = (mf.x & PR_MF_FRONT) ? tn2 : neg3(tn2);   // precomputed; normalize(-n) == -normalize(n) exactly
+            if (hit_tri) lnormal = (hitp & HITP_FRONT) ? tn2 : neg3(tn2);   // precomputed; normalize(-n) == -normalize(n) exactly
             else lnormal = normalize3(nrm);
             const double lightPower = fmax(0.0, dot3(lnormal, rd));
             d3 contrib;
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         }
         if (need_scatter) {                                  // Trace.hs:27-76
           RT_COLD_ARGS();
-          const bool front = (mf.x & PR_MF_FRONT) != 0;
+          const bool front = (hitp & HITP_FRONT) != 0;
           // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
           //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)
           {
