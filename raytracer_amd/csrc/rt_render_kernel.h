@@ -59,6 +59,9 @@
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 24    // idle lanes are given new items once this many wait (or none is live): the refill costs the whole wave
 #endif
+#ifndef RT_BLOCKS_PER_CU
+#define RT_BLOCKS_PER_CU 1    // workgroups resident per CU (each gets 160 KB / RT_BLOCKS_PER_CU of LDS)
+#endif
 #ifndef RT_BLOCK_THREADS
 #define RT_BLOCK_THREADS (256 * RT_MIN_WAVES)   // one workgroup per CU
 #endif

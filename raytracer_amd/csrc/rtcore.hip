@@ -404,12 +404,13 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   const size_t stack_bytes = (size_t)fr.stack_depth * 64 * sizeof(uint2);
   int wpb = RT_BLOCK_THREADS / 64;
   if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env)));   // experiment knob
-  while (wpb > 4 && (size_t)wpb * stack_bytes > 150 * 1024) --wpb;
+  const size_t lds_cu = 160 * 1024 / RT_BLOCKS_PER_CU;       // LDS one workgroup may use
+  while (wpb > 4 && (size_t)wpb * stack_bytes > lds_cu - 6 * 1024) --wpb;
   const int threads = wpb * 64;
   const size_t lds_waves = (size_t)wpb * stack_bytes;
   fr.top_nodes = 0;
-  if (sizeof(BT) == 4 && lds_waves < 156 * 1024) {
-    size_t room = (156 * 1024 - lds_waves) / sizeof(DNode<float>);
+  if (sizeof(BT) == 4 && lds_waves < lds_cu - 4 * 1024) {
+    size_t room = (lds_cu - 4 * 1024 - lds_waves) / sizeof(DNode<float>);
     int cap = RT_TOP_NODES_MAX;
     const char *env = getenv("RT_TOP_NODES");               // experiment knob
     if (env) cap = atoi(env);
@@ -417,12 +418,13 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   }
   size_t lds = lds_waves + (size_t)fr.top_nodes * sizeof(DNode<float>);
   if (const char *pad = getenv("RT_LDS_BYTES")) lds = std::max(lds, (size_t)atol(pad));   // experiment knob: caps blocks per CU
-  if (lds > 160 * 1024) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
+  if (lds > lds_cu) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
   auto kern = k_render_tiles<BT, STATS>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
   per_cu = std::max(1, per_cu);
+  if (getenv("RT_DEBUG")) fprintf(stderr, "rtcore: %d threads/workgroup, %zu B LDS (%d cached nodes), %d workgroups/CU\n", threads, lds, fr.top_nodes, per_cu);
 
   // tiles per launch from the sample-buffer budget
   const size_t bytes_per_tile = (size_t)64 * fr.spp * 3 * sizeof(double);
