@@ -42,7 +42,8 @@ struct KFrame {
   int32_t *out_primid;
   uint32_t *tile_counter;      // hands out chunks of items
   unsigned long long *stats;   // STAT_COUNT counters, see STAT_*
-  double *fscratch;            // [grid waves][PR_ROWS][64] doubles: the per-lane path records
+  double *fscratch;            // [grid waves][scratch_rows][64] x 8 B: the records' cold rows (PR_ROWS), then the stack overflow rows
+  int32_t scratch_rows;        // PR_ROWS + max(0, stack_depth - RT_STACK_LDS)
   int32_t stack_depth;
   int32_t top_nodes;           // the first top_nodes internal nodes (top levels, breadth-first) are cached in LDS
   // one launch covers the local tiles [tile_begin, tile_end) of this rank's list: items = (tile, position, sample)

@@ -50,6 +50,9 @@
 #ifndef RT_CHUNK
 #define RT_CHUNK 1024u      // items a wave takes from the global counter at a time (multiple of 64)
 #endif
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 6      // traversal-stack entries kept in LDS; deeper entries (4.6 % of the pushes on C4) go to global memory
+#endif
 #ifndef RT_POPS
 #define RT_POPS 1           // inline predicated pops per step; a lane whose popped entries were all culled continues as CUR_POP
 #endif
@@ -82,8 +85,10 @@
 // rows of the per-lane path record (doubles; 64 lanes per row)
 #ifndef RT_REC_ROWS_DEFINED
 #define RT_REC_ROWS_DEFINED
-enum { PR_UDIR = 0, PR_NRM = 3, PR_ATT = 6, PR_FA = 9, PR_FL = 12, PR_FH = 15, PR_SB = 18 /* int2: sample, bounce */,
-       PR_ROWS = 19 };
+// The per-lane path record.  Its hot rows live in LDS next to the traversal stack ([wave][row][lane], doubles);
+// the rows only spheres / planes / glass / metal use stay in global memory, followed by the stack's overflow rows.
+enum { LR_ATT = 0, LR_FA = 3, LR_FL = 6, LR_FH = 9, LR_SB = 12 /* int2: sample, bounce */, LR_ROWS = 13 };
+enum { PR_UDIR = 0, PR_NRM = 3, PR_ROWS = 6 };
 #define HITP_FRONT ((int)0x80000000)   // lane register hitp: the primitive of the path's current hit | front-face bit
 
 RT_DEV d3 rec_ld(const double *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
@@ -123,11 +128,13 @@ __device__ __attribute__((noinline)) double pow_gamma(double c, double g) { retu
 
 template <typename BT, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
-  extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: [entry][lane] stack
+  extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: RT_STACK_LDS stack rows + LR_ROWS record rows
   const int lane = threadIdx.x & 63;
   const float4 *lnodes = (const float4 *)lds_all;          // 4 x float4 per cached FP32 node
-  uint2 *stack = lds_all + (size_t)fr.top_nodes * 8 + (size_t)(threadIdx.x >> 6) * fr.stack_depth * 64 + lane;
-  double *rec = fr.fscratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PR_ROWS * 64 + lane;
+  uint2 *stack = lds_all + (size_t)fr.top_nodes * 8 + (size_t)(threadIdx.x >> 6) * (RT_STACK_LDS + LR_ROWS) * 64 + lane;
+  double *lrec = (double *)(stack + RT_STACK_LDS * 64);    // this lane's hot record rows (LDS)
+  double *rec = fr.fscratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * fr.scratch_rows * 64 + lane;
+  uint2 *ovf = (uint2 *)(rec + PR_ROWS * 64);              // stack entries RT_STACK_LDS, RT_STACK_LDS + 1, ... of this lane
   const DNode<BT> *nodes = (const DNode<BT> *)sc.nodes;
   const int top_nodes_v = fr.top_nodes;
   const double inf = __builtin_huge_val();
@@ -176,7 +183,10 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   do {                                                                               \
     _Pragma("unroll") for (int a_ = 0; a_ < RT_POPS; ++a_) {                               \
       const int spn_ = sp - 1;                                                       \
-      const uint2 e_ = stack[(spn_ < 0 ? 0 : spn_) * 64];                            \
+      uint2 e_ = stack[(spn_ < 0 ? 0 : (spn_ < RT_STACK_LDS ? spn_ : RT_STACK_LDS - 1)) * 64]; \
+      if (__ballot((p_) && spn_ >= RT_STACK_LDS) != 0ull) {          /* rare: the entry is in the overflow rows */ \
+        if ((p_) && spn_ >= RT_STACK_LDS) e_ = ovf[(spn_ - RT_STACK_LDS) * 64];      \
+      }                                                                              \
       const bool empty_ = sp == 0;                                                   \
       const bool culled_ = cull_entry(__uint_as_float(e_.y), tmaxb);                 \
       cur = (p_) ? (empty_ ? CUR_DONE : (culled_ ? cur : (int)e_.x)) : cur;          \
@@ -232,9 +242,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (smp == 0u && fr.out_primid) fr.out_primid[fr.packed ? gt * 64u + pos : pixel] = -1;
           camera_ray(fr, px, py, pixel, smp, ro, rd);
           if (fr.maxb > 0) {
-            rec_st(rec, PR_ATT, mk3(1, 1, 1)); rec_st(rec, PR_FA, mk3(0, 0, 0));
-            rec_st(rec, PR_FL, mk3(-inf, -inf, -inf)); rec_st(rec, PR_FH, mk3(inf, inf, inf));
-            rec_sti(rec, PR_SB, (int)smp, 0);
+            rec_st(lrec, LR_ATT, mk3(1, 1, 1)); rec_st(lrec, LR_FA, mk3(0, 0, 0));
+            rec_st(lrec, LR_FL, mk3(-inf, -inf, -inf)); rec_st(lrec, LR_FH, mk3(inf, inf, inf));
+            rec_sti(lrec, LR_SB, (int)smp, 0);
             li = -1;
             RT_BEGIN_QUERY(RT_TMAX);
           } else {
@@ -285,9 +295,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         // ---- All memory this trip can need is requested up front, in two rounds of independent loads, instead of one
         // dependent round trip per use: SHADE is latency bound (records and scene compete for 4 MB of L2 per XCD).
         // Round 1: the whole record and the header of the hit primitive.
-        int2 sb = rec_ldi(r, PR_SB);
-        d3 fa = rec_ld(r, PR_FA), att = rec_ld(r, PR_ATT), nrm = mk3(0, 0, 0);
-        d3 fl = rec_ld(r, PR_FL), fh = rec_ld(r, PR_FH);
+        int2 sb = rec_ldi(lrec, LR_SB);
+        d3 fa = rec_ld(lrec, LR_FA), att = rec_ld(lrec, LR_ATT), nrm = mk3(0, 0, 0);
+        d3 fl = rec_ld(lrec, LR_FL), fh = rec_ld(lrec, LR_FH);
         int2 pkm;                                            // (material, kind) of the hit primitive
         d3 tn, tn2;                                          // triangles: face normal n (Triangle.hs:51) and normalize(n) (Light.hs:19)
         DMaterial M;
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
               rec_st(r, PR_UDIR, normalize3(rd));
             hitp = best | (front ? HITP_FRONT : 0);
             fa = fa + ld3(M.emission);                       // emitted (Trace.hs:29) joins the pending offset
-            rec_st(r, PR_FA, fa);
+            rec_st(lrec, LR_FA, fa);
             ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
             if (STATS) st[STAT_SHADED]++;
             if (sc.n_lights > 0) li = sc.n_lights - 1; else need_scatter = true;
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
               contrib = lightPower * ld3(L.intensity);
             }
             fa = fa + ld3(M.diffuse) * contrib;              // litColor = surfaceColor * directLight (Trace.hs:36), light by light
-            rec_st(r, PR_FA, fa);
+            rec_st(lrec, LR_FA, fa);
           }
           --li;
           if (li < 0) need_scatter = true;
@@ -377,8 +387,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           {
             const d3 nl = clamp3(fa, fl, fh), nh = clamp3(mk3(fa.x + 10.0, fa.y + 10.0, fa.z + 10.0), fl, fh);
             fl = nl; fh = nh;
-            rec_st(r, PR_FL, fl);
-            rec_st(r, PR_FH, fh);
+            rec_st(lrec, LR_FL, fl);
+            rec_st(lrec, LR_FH, fh);
           }
           const u4 w = philox4x32_10(pixel, (uint32_t)sb.x, 1u + (uint32_t)sb.y, 0u, fr.key0, fr.key1);
           const d3 randVec = normalize3(mk3(um11(w.x), um11(w.y), um11(w.z)));   // :38-42
@@ -399,9 +409,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           } else {                                                               // :65-67
             rd = normalize3(nrm + randVec);
           }
-          if (!(M.flags & DMAT_NO_ATTEN)) { att = att * ld3(M.diffuse); rec_st(r, PR_ATT, att); }   // :69-72
+          if (!(M.flags & DMAT_NO_ATTEN)) { att = att * ld3(M.diffuse); rec_st(lrec, LR_ATT, att); }   // :69-72
           sb.y += 1;
-          rec_sti(r, PR_SB, sb.x, sb.y);
+          rec_sti(lrec, LR_SB, sb.x, sb.y);
           li = -1;
           if (sb.y >= fr.maxb) { need_ray0 = true; need_finish = true; }         // depth 0: background along ray0, :22
         }
@@ -471,7 +481,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           const BT ts = lf ? tR : tL;
           float tsf;
           if constexpr (sizeof(BT) == 8) tsf = __double2float_rd((double)ts); else tsf = (float)ts;
-          stack[sp * 64] = make_uint2((uint32_t)(lf ? refR : refL), __float_as_uint(tsf));
+          const uint2 ent = make_uint2((uint32_t)(lf ? refR : refL), __float_as_uint(tsf));
+          if (sp < RT_STACK_LDS) stack[sp * 64] = ent; else ovf[(sp - RT_STACK_LDS) * 64] = ent;
           ++sp;
         }
         cur = (hL || hR) ? ((hL && (lf || !hR)) ? refL : refR) : cur;

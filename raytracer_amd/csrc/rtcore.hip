@@ -84,6 +84,7 @@ struct rt_scene {
   unsigned long long *d_stats = nullptr;
   double *d_fscratch = nullptr;         // per resident wave: the lanes' path records (rt_render_kernel.h)
   size_t fscratch_waves = 0;
+  int fscratch_rows = 0;
   double *d_samples = nullptr;          // radiance of every path of one launch, [item][3]
   size_t samples_cap = 0;               // bytes
   // cached outputs of rt_render
@@ -401,7 +402,9 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   KFrame fr = fr_in;
   // One workgroup per CU, RT_MIN_WAVES waves per SIMD; deep trees (long per-lane stacks) get fewer waves so that the
   // stacks still fit the CU's LDS.  What is left of 160 KB caches the top BVH levels.
-  const size_t stack_bytes = (size_t)fr.stack_depth * 64 * sizeof(uint2);
+  // per wave: RT_STACK_LDS stack rows + the record's hot rows; deeper stack entries overflow to global memory
+  const size_t stack_bytes = (size_t)(RT_STACK_LDS + LR_ROWS) * 64 * sizeof(uint2);
+  fr.scratch_rows = PR_ROWS + std::max(0, fr.stack_depth - RT_STACK_LDS);
   int wpb = RT_BLOCK_THREADS / 64;
   if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env)));   // experiment knob
   const size_t lds_cu = 160 * 1024 / RT_BLOCKS_PER_CU;       // LDS one workgroup may use
@@ -453,11 +456,11 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   const size_t waves_first = (tpp * 64 * (size_t)fr.spp + 63) / 64;           // wave-loads of items in the largest launch
   const int grid_max = (int)std::max<size_t>(1, std::min<size_t>((waves_first + wpb - 1) / wpb, (size_t)g_ctx.n_cu * per_cu));
   const size_t waves = (size_t)grid_max * wpb;
-  if (waves > s->fscratch_waves) {      // grows only on the first launch / a larger grid; never inside a steady-state loop
+  if (waves > s->fscratch_waves || fr.scratch_rows > s->fscratch_rows) {      // grows only on the first launch / a larger grid; never inside a steady-state loop
     HIP_TRY(hipStreamSynchronize(stream));
     (void)hipFree(s->d_fscratch); s->d_fscratch = nullptr; s->fscratch_waves = 0;
-    if (hipMalloc((void **)&s->d_fscratch, waves * PR_ROWS * 64 * sizeof(double)) != hipSuccess) return fail(RT_ERR_OOM, "path records for %zu waves", waves);
-    s->fscratch_waves = waves;
+    if (hipMalloc((void **)&s->d_fscratch, waves * fr.scratch_rows * 64 * sizeof(double)) != hipSuccess) return fail(RT_ERR_OOM, "path records for %zu waves", waves);
+    s->fscratch_waves = waves; s->fscratch_rows = fr.scratch_rows;
   }
   fr.fscratch = s->d_fscratch;
   if (STATS) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
