@@ -138,7 +138,9 @@ typedef struct rt_params {
   double   gamma;             /* gammaCorrect, Trace.hs:103-105 (used as the exponent) */
   uint64_t seed;
   int32_t  collect_stats;     /* 1: also count rays / nodes / prim tests (slower kernel variant) */
-  int32_t  box_precision;     /* 0: default (FP32 conservative boxes); 1: FP64 boxes, exact reference slab test */
+  int32_t  box_precision;     /* 0: default (the core's own SAH tree, FP32 conservative boxes, reference tie rule);
+                                 1: the reference's tree with FP64 boxes, exact reference slab test, exactly its node visits;
+                                 2: the reference's tree with FP32 conservative boxes.  All three give the same image. */
 } rt_params;
 
 /* Caller-allocated outputs, any of them may be NULL. */

@@ -1,0 +1,146 @@
+// rt_fastbvh.h — host-side builder of the render core's OWN acceleration structure (binned SAH, binary).
+//
+// The reference's tree (median split on the centroid, Hittable/BVH.hs:29-103) decides RESULTS only through two
+// things: which primitive wins when several are hit at exactly the same distance (traversal order), and the leaf
+// box that bounds a plane (Plane.hs:20).  Everything else is "the closest accepted hit", which any conservative
+// structure over the same primitives finds.  The kernel therefore traverses this tree and settles exact ties with
+// the reference tree (rt_render_kernel.h: tie_candidate_wins); planes enter with the box of their reference leaf.
+// On the metric scene (63,432 triangles, 20 of them room-sized) the median split visits 22.95 nodes and tests 7.78
+// primitives per ray, this tree 5.8 and 1.3 for the same rays and the same hits.
+//
+// Node numbering: the subtree over the slots [lo, hi) of `order` has its root at index `base`, its left subtree at
+// base + 1 and its right subtree at base + 2 * (mid - lo): regions are disjoint, so subtrees are built by independent
+// threads without synchronisation; unused indices keep child[2i] == 0 && child[2i+1] == 0 and are skipped by the
+// caller's re-ordering pass.  A leaf's primitives are the slots [lo, hi) themselves.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <future>
+#include <vector>
+
+struct FastBvh {
+  std::vector<double> bounds;    // 6 per node: the node's own box (lo.xyz, hi.xyz)
+  std::vector<int32_t> child;    // 2 per node: internal (left, right) | leaf (-1 - first_slot, count) | unused (0, 0)
+  std::vector<int32_t> order;    // slot -> primitive index
+  int depth = 0;
+};
+
+namespace fastbvh {
+
+struct Box {
+  double lo[3], hi[3];
+  void reset() { for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; } }
+  void grow(const double *b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b[k]); hi[k] = std::max(hi[k], b[3 + k]); } }
+  void grow(const Box &b) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); } }
+  double area() const {
+    const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x * y + y * z + z * x;
+  }
+};
+
+struct Builder {
+  static constexpr int NBINS = 32;
+  const double *boxes;           // 6 per primitive
+  std::vector<float> cen;        // 3 per primitive: box centre (only steers the partition, never a result)
+  FastBvh *out;
+  int max_leaf;
+  double cost_isect, cost_trav;
+  int par_depth;                 // spawn threads for subtrees above this depth
+
+  int bin_of(float c, float lo, float scale) const { return std::min(NBINS - 1, std::max(0, (int)((c - lo) * scale))); }
+
+  int build(int lo, int hi, int base, int depth) {
+    int32_t *order = out->order.data();
+    const int n = hi - lo;
+    Box b, cb;
+    b.reset(); cb.reset();
+    for (int i = lo; i < hi; ++i) {
+      const int p = order[i];
+      b.grow(boxes + 6 * (size_t)p);
+      for (int k = 0; k < 3; ++k) { const double c = cen[3 * (size_t)p + k]; cb.lo[k] = std::min(cb.lo[k], c); cb.hi[k] = std::max(cb.hi[k], c); }
+    }
+    for (int k = 0; k < 3; ++k) { out->bounds[6 * (size_t)base + k] = b.lo[k]; out->bounds[6 * (size_t)base + 3 + k] = b.hi[k]; }
+    auto make_leaf = [&]() { out->child[2 * (size_t)base] = -1 - lo; out->child[2 * (size_t)base + 1] = n; return depth; };
+    if (n == 1) return make_leaf();
+
+    int mid = -1;
+    if (depth < 40) {                      // SAH over NBINS centroid bins per axis; deeper: balanced halves (bounds the stack)
+      double best_cost = INFINITY;
+      int best_axis = -1, best_bin = -1;
+      for (int ax = 0; ax < 3; ++ax) {
+        const float clo = (float)cb.lo[ax], ext = (float)cb.hi[ax] - clo;
+        if (!(ext > 0.0f)) continue;
+        const float scale = (float)NBINS / ext;
+        Box bb[NBINS];
+        int cnt[NBINS];
+        for (int i = 0; i < NBINS; ++i) { bb[i].reset(); cnt[i] = 0; }
+        for (int i = lo; i < hi; ++i) {
+          const int p = order[i], q = bin_of(cen[3 * (size_t)p + ax], clo, scale);
+          bb[q].grow(boxes + 6 * (size_t)p);
+          cnt[q]++;
+        }
+        double r_area[NBINS];
+        int r_cnt[NBINS];
+        Box acc;
+        acc.reset();
+        int c = 0;
+        for (int i = NBINS - 1; i > 0; --i) { acc.grow(bb[i]); c += cnt[i]; r_area[i] = c ? acc.area() : 0.0; r_cnt[i] = c; }
+        acc.reset(); c = 0;
+        for (int i = 0; i + 1 < NBINS; ++i) {
+          acc.grow(bb[i]); c += cnt[i];
+          if (c == 0 || r_cnt[i + 1] == 0) continue;
+          const double cost = acc.area() * c + r_area[i + 1] * r_cnt[i + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = i; }
+        }
+      }
+      if (best_axis >= 0) {
+        const double leaf_cost = cost_isect * n * b.area(), split_cost = cost_trav * b.area() + cost_isect * best_cost;
+        if (n <= max_leaf && leaf_cost <= split_cost) return make_leaf();
+        const float clo = (float)cb.lo[best_axis], scale = (float)NBINS / ((float)cb.hi[best_axis] - clo);
+        mid = (int)(std::partition(order + lo, order + hi, [&](int p) { return bin_of(cen[3 * (size_t)p + best_axis], clo, scale) <= best_bin; }) - order);
+      } else if (n <= max_leaf) {
+        return make_leaf();                // all centres coincide (duplicates)
+      }
+    } else if (n <= max_leaf) {
+      return make_leaf();
+    }
+    if (mid <= lo || mid >= hi) mid = lo + n / 2;
+    const int lbase = base + 1, rbase = base + 2 * (mid - lo);
+    out->child[2 * (size_t)base] = lbase;
+    out->child[2 * (size_t)base + 1] = rbase;
+    int dl, dr;
+    if (depth < par_depth && n > 8192) {
+      auto fut = std::async(std::launch::async, [=]() { return build(lo, mid, lbase, depth + 1); });
+      dr = build(mid, hi, rbase, depth + 1);
+      dl = fut.get();
+    } else {
+      dl = build(lo, mid, lbase, depth + 1);
+      dr = build(mid, hi, rbase, depth + 1);
+    }
+    return std::max(dl, dr);
+  }
+};
+
+}  // namespace fastbvh
+
+// boxes: 6 doubles per primitive (lo.xyz, hi.xyz), finite.  max_leaf >= 1.  n_threads <= 1: serial.
+inline void build_fast_bvh(int n_prims, const double *boxes, int max_leaf, int n_threads, FastBvh &out) {
+  out.bounds.assign((size_t)12 * n_prims, 0.0);
+  out.child.assign((size_t)4 * n_prims, 0);
+  out.order.resize(n_prims);
+  for (int i = 0; i < n_prims; ++i) out.order[i] = i;
+  fastbvh::Builder B;
+  B.boxes = boxes;
+  B.cen.resize((size_t)3 * n_prims);
+  for (int i = 0; i < n_prims; ++i)
+    for (int k = 0; k < 3; ++k) B.cen[3 * (size_t)i + k] = (float)(0.5 * (boxes[6 * (size_t)i + k] + boxes[6 * (size_t)i + 3 + k]));
+  B.out = &out;
+  B.max_leaf = std::max(1, max_leaf);
+  B.cost_isect = 1.2;   // one FP64 primitive test against one two-box node visit, in kernel instructions
+  B.cost_trav = 1.0;
+  int pd = 0;
+  while ((1 << pd) < n_threads) ++pd;
+  B.par_depth = n_threads > 1 ? pd + 2 : 0;
+  out.depth = B.build(0, n_prims, 0, 0);
+}

@@ -15,8 +15,14 @@
 #include "../../include/rtcore.h"
 
 struct KScene {
-  const void *nodes;           // DNode<BT>[]
-  const DPrim *prims;
+  const void *nodes;           // DNode<BT>[] of the tree the kernel traverses
+  const DPrim *prims;          // primitives in the reference's leaf order (shading reads these)
+  const DPrim *tprims;         // primitives in the traversed tree's leaf order (FAST: .mat = index into prims; else == prims)
+  // FAST only: the reference tree, consulted when two primitives are hit at exactly the same distance
+  const void *ref_nodes64;     // DNode<double>[]: both children's FP64 boxes per internal node
+  const int32_t *ref_anc;      // per internal node: (parent << 1) | side (0 = left child), root: -1
+  const int32_t *ref_depth;    // per internal node: edges from the root
+  const int32_t *leaf_anc;     // per primitive: (parent of its leaf << 1) | side
   const int32_t *prim_ids;
   const DMaterial *mats;
   const DLight *lights;

@@ -126,7 +126,36 @@ __device__ __attribute__((noinline)) double pow_gamma(double c, double g) { retu
 #define RT_COLD_ARGS() do { } while (0)
 #endif
 
-template <typename BT, bool STATS>
+// An exact tie in FAST mode (this kernel's own tree): would the reference have kept `cand` over `cur`, both hit at the
+// same distance?  The reference keeps the one it tests LATER (HitHelpers.hs:14-16: `t <= closest`; BVH.hs:137-141: the
+// child visited second receives [min, t1] and wins an equal t).  Same reference leaf: the later element.  Different
+// leaves: at their lowest common ancestor the child with the smaller entry distance is visited first, tie => right
+// first (BVH.hs:132); a child's clipped interval starts at max(its own slab entry, 0.001) whatever its ancestors
+// clipped, because nested boxes give nested slab intervals.  Out of line and rare: duplicated objects (the reference
+// lists config triangles twice, SceneParser.hs:67-73) and rays through shared edges or vertices.
+__device__ __attribute__((noinline)) bool tie_candidate_wins(const int32_t *leaf_anc, const int32_t *ref_anc, const int32_t *ref_depth,
+                                                             const DNode<double> *ref_nodes, double ox, double oy, double oz,
+                                                             double dx, double dy, double dz, int cand, int cur) {
+  const int a = leaf_anc[cur], c = leaf_anc[cand];
+  if (a == c) return cand > cur;
+  int na = a >> 1, nc = c >> 1, side_c = c & 1;
+  for (int guard = 0; na != nc && guard < 256; ++guard) {
+    if (ref_depth[na] >= ref_depth[nc]) na = ref_anc[na] >> 1;
+    else { const int x = ref_anc[nc]; side_c = x & 1; nc = x >> 1; }
+  }
+  BoxRay<double> br;
+  make_boxray(br, mk3(ox, oy, oz), mk3(dx, dy, dz), 0.0f);
+  const double *bx = ref_nodes[na].box;
+  double eL, eR;
+  (void)box_test(br, bx, RT_TMIN, __builtin_huge_val(), eL);
+  (void)box_test(br, bx + 6, RT_TMIN, __builtin_huge_val(), eR);
+  const bool left_first = eL < eR;
+  return side_c == (left_first ? 1 : 0);
+}
+
+// FAST: the kernel traverses the render core's own SAH tree (rt_fastbvh.h); primitives carry their index in the
+// reference's leaf order, and exact ties are settled as the reference's traversal would (tie_candidate_wins).
+template <typename BT, bool STATS, bool FAST>
 __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
   extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: RT_STACK_LDS stack rows + LR_ROWS record rows
   const int lane = threadIdx.x & 63;
@@ -502,7 +531,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_POP;
         const int pi = ~(use_p ? pend : cur);
         // lanes not in a leaf read primitive 0 (always present) and discard the result: see the NODE body
-        const DPrim P = *(const DPrim *)((const char *)sc.prims + (size_t)((uint32_t)(isl ? pi : 0) * 80u));
+        const DPrim P = *(const DPrim *)((const char *)sc.tprims + (size_t)((uint32_t)(isl ? pi : 0) * 80u));
         const uint32_t kind = P.kind & DPRIM_KIND_MASK;
         // Moller-Trumbore without early exits (Triangle.hs:30-53): same operations, same order, the rejections become one predicate
         double t;
@@ -525,8 +554,15 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           else if (isl && kind == RT_PRIM_PLANE) { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro, rd, RT_TMIN, best_t, t); }
         }
         h = h && isl;
+        if constexpr (FAST) {                                // this tree's order is not the reference's: settle exact ties its way
+          const bool tie = h && li < 0 && best >= 0 && t == best_t;
+          if (__ballot(tie) != 0ull) {
+            if (tie) h = tie_candidate_wins(sc.leaf_anc, sc.ref_anc, sc.ref_depth, (const DNode<double> *)sc.ref_nodes64,
+                                            ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, P.mat, best);
+          }
+        }
         best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
-        best = h ? pi : best;
+        best = h ? (FAST ? P.mat : pi) : best;               // FAST: the slot holds the primitive's index in the reference's order
         tmaxb = h ? tmax_for_boxes<BT>(t) : tmaxb;
         const bool blocked = h && li >= 0;                   // shadow ray: any hit blocks (Light.hs:30-32)
         const bool last = (P.kind & DPRIM_LAST) != 0u;

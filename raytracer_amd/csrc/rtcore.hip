@@ -17,6 +17,8 @@
 #define RT_TOP_NODES_MAX 1023
 #endif
 #include "rt_kernels.h"
+#include "rt_fastbvh.h"
+#include <thread>
 
 namespace {
 
@@ -68,15 +70,20 @@ struct rt_scene {
   int device = 0;
   // HBM-resident scene
   DNode<float> *d_nodes32 = nullptr;
-  DNode<double> *d_nodes64 = nullptr;   // uploaded on first use of box_precision = 1
+  DNode<double> *d_nodes64 = nullptr;   // the reference tree's FP64 boxes: box_precision = 1 and the tie rule of the fast tree
   DPrim *d_prims = nullptr;
+  // the render core's own tree (rt_fastbvh.h); absent when the reference root is a leaf
+  bool has_fast = false;
+  DNode<float> *d_fnodes32 = nullptr;
+  DPrim *d_fprims = nullptr;
+  int32_t *d_ref_anc = nullptr, *d_ref_depth = nullptr, *d_leaf_anc = nullptr;
+  int f_internal = 0, f_depth = 0, f_root_ref = 0;
   int32_t *d_prim_ids = nullptr;
   DMaterial *d_mats = nullptr;
   DLight *d_lights = nullptr;
   double *d_plane_boxes = nullptr;
   double *d_tri_normals = nullptr;
   void *d_sky = nullptr;
-  std::vector<DNode<double>> h_nodes64;
   KScene ks{};
   int n_internal = 0, depth = 0;
   // per-launch scratch
@@ -128,6 +135,7 @@ void rt_shutdown(void) { g_ctx.ready = false; }
 void rt_scene_destroy(rt_scene *s) {
   if (!s) return;
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
+  (void)hipFree(s->d_fnodes32); (void)hipFree(s->d_fprims); (void)hipFree(s->d_ref_anc); (void)hipFree(s->d_ref_depth); (void)hipFree(s->d_leaf_anc);
   (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky);
   (void)hipFree(s->d_counter); (void)hipFree(s->d_stats); (void)hipFree(s->d_fscratch); (void)hipFree(s->d_samples);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_tiles);
@@ -290,9 +298,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   // ---- internal nodes: children's boxes, FP64 as given and FP32 rounded outward
   const int ni = std::max(1, s->n_internal);
   std::vector<DNode<float>> n32(ni);
-  s->h_nodes64.assign(ni, DNode<double>());
+  std::vector<DNode<double>> n64(ni);
   std::memset(n32.data(), 0, ni * sizeof(DNode<float>));
-  std::memset(s->h_nodes64.data(), 0, ni * sizeof(DNode<double>));
+  std::memset(n64.data(), 0, ni * sizeof(DNode<double>));
+  // where each internal node and each primitive hangs in the reference tree (the fast tree's tie rule climbs these)
+  std::vector<int32_t> ref_anc(ni, -1), ref_depth(ni, 0), leaf_anc(np, 0);
   auto ref_of = [&](int child) -> int32_t { return is_leaf(child) ? d->node_child[2 * child] : dev_index[child]; };   // leaf: -1-first == ~first
   for (int k = 0; k < s->n_internal; ++k) {
     int i = order[k];
@@ -300,14 +310,101 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
       int child = d->node_child[2 * i + c];
       const double *b = d->node_bounds + 6 * (size_t)child;
       for (int q = 0; q < 3; ++q) {
-        s->h_nodes64[k].box[6 * c + q] = b[q];
-        s->h_nodes64[k].box[6 * c + 3 + q] = b[3 + q];
+        n64[k].box[6 * c + q] = b[q];
+        n64[k].box[6 * c + 3 + q] = b[3 + q];
         n32[k].box[6 * c + q] = f32_down(b[q]);
         n32[k].box[6 * c + 3 + q] = f32_up(b[3 + q]);
       }
-      s->h_nodes64[k].ref[c] = n32[k].ref[c] = ref_of(child);
+      n64[k].ref[c] = n32[k].ref[c] = ref_of(child);
+      if (is_leaf(child)) {
+        long first = -1L - d->node_child[2 * child], cnt = d->node_child[2 * child + 1];
+        for (long q = first; q < first + cnt; ++q) leaf_anc[q] = (k << 1) | c;
+      } else {
+        ref_anc[dev_index[child]] = (k << 1) | c;     // parents precede their children in `order`
+        ref_depth[dev_index[child]] = ref_depth[k] + 1;
+      }
     }
   }
+
+  // ---- the render core's own tree over the same primitives (rt_fastbvh.h).  Boxes: triangles as Triangle.hs:24-28
+  //      (vertex extent padded by 1e-8), spheres as Sphere.hs:20-22, planes by the box of their reference leaf -
+  //      the only region where the reference can see them (Plane.hs:20).
+  FastBvh fb;
+  std::vector<DNode<float>> fn32(1);
+  std::vector<DPrim> fprims;
+  std::memset(fn32.data(), 0, sizeof(DNode<float>));
+  bool fast_ok = !is_leaf(0);
+  if (fast_ok) {
+    std::vector<double> pbox((size_t)np * 6);
+    for (int i = 0; i < np && fast_ok; ++i) {
+      double *b = &pbox[6 * (size_t)i];
+      const uint32_t kind = prims[i].kind & DPRIM_KIND_MASK;
+      if (kind == RT_PRIM_TRIANGLE) {
+        const double *v = d->prim_data + 9 * (size_t)i;
+        for (int q = 0; q < 3; ++q) {
+          b[q] = std::min(v[q], std::min(v[3 + q], v[6 + q])) - 1e-8;
+          b[3 + q] = std::max(v[q], std::max(v[3 + q], v[6 + q])) + 1e-8;
+        }
+      } else if (kind == RT_PRIM_SPHERE) {
+        const double r = std::fabs(prims[i].d[3]);
+        for (int q = 0; q < 3; ++q) { b[q] = prims[i].d[q] - r; b[3 + q] = prims[i].d[q] + r; }
+      } else {
+        const double *lb = &plane_boxes[6 * (size_t)prims[i].d[6]];
+        for (int q = 0; q < 6; ++q) b[q] = lb[q];
+      }
+      for (int q = 0; q < 6; ++q) if (!std::isfinite(b[q])) fast_ok = false;
+    }
+    if (fast_ok) {
+      int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+      if (const char *env = getenv("RT_BUILD_THREADS")) nt = std::max(1, atoi(env));
+      build_fast_bvh(np, pbox.data(), 4, nt, fb);
+      if (fb.depth > 60) fast_ok = false;
+    }
+  }
+  if (fast_ok) {
+    // internal nodes: the top levels breadth-first (LDS cache), the subtrees below depth-first, as for the reference tree
+    auto f_leaf = [&](int i) { return fb.child[2 * (size_t)i] < 0; };
+    std::vector<int> f_order, f_index(fb.child.size() / 2, -1), fr_{0}, f_deep;
+    for (int lv = 0; !fr_.empty(); ++lv) {
+      std::vector<int> next;
+      for (int i : fr_) {
+        if (f_leaf(i)) continue;
+        if (lv >= TOP_LEVELS) { f_deep.push_back(i); continue; }
+        f_index[i] = (int)f_order.size(); f_order.push_back(i);
+        next.push_back(fb.child[2 * (size_t)i]); next.push_back(fb.child[2 * (size_t)i + 1]);
+      }
+      fr_.swap(next);
+    }
+    for (int r : f_deep) {
+      std::vector<int> stk{r};
+      while (!stk.empty()) {
+        int i = stk.back(); stk.pop_back();
+        if (f_leaf(i)) continue;
+        f_index[i] = (int)f_order.size(); f_order.push_back(i);
+        stk.push_back(fb.child[2 * (size_t)i + 1]); stk.push_back(fb.child[2 * (size_t)i]);
+      }
+    }
+    s->f_internal = (int)f_order.size();
+    s->f_depth = fb.depth;
+    s->f_root_ref = f_leaf(0) ? fb.child[0] : 0;
+    fn32.assign(std::max(1, s->f_internal), DNode<float>());
+    std::memset(fn32.data(), 0, fn32.size() * sizeof(DNode<float>));
+    for (int k = 0; k < s->f_internal; ++k) {
+      const int i = f_order[k];
+      for (int c = 0; c < 2; ++c) {
+        const int child = fb.child[2 * (size_t)i + c];
+        const double *b = &fb.bounds[6 * (size_t)child];
+        for (int q = 0; q < 3; ++q) { fn32[k].box[6 * c + q] = f32_down(b[q]); fn32[k].box[6 * c + 3 + q] = f32_up(b[3 + q]); }
+        fn32[k].ref[c] = f_leaf(child) ? fb.child[2 * (size_t)child] : f_index[child];
+      }
+    }
+    // primitives in this tree's leaf order; the material slot carries the index in the reference's order instead
+    fprims.resize(np);
+    for (int q = 0; q < np; ++q) { fprims[q] = prims[fb.order[q]]; fprims[q].mat = fb.order[q]; fprims[q].kind &= ~DPRIM_LAST; }
+    for (size_t i = 0; i < fb.child.size() / 2; ++i)
+      if (f_leaf((int)i)) fprims[(size_t)(-1 - fb.child[2 * i]) + fb.child[2 * i + 1] - 1].kind |= DPRIM_LAST;
+  }
+  s->has_fast = fast_ok;
 
   std::vector<DLight> lights(std::max(1, d->n_lights));
   std::memset(lights.data(), 0, lights.size() * sizeof(DLight));
@@ -319,6 +416,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
 
 #define UP(call) do { if ((rc = (call))) { rt_scene_destroy(s); return rc; } } while (0)
   UP(dev_upload(&s->d_nodes32, n32.data(), (size_t)ni));
+  UP(dev_upload(&s->d_nodes64, n64.data(), (size_t)ni));
+  if (fast_ok) {
+    UP(dev_upload(&s->d_fnodes32, fn32.data(), fn32.size()));
+    UP(dev_upload(&s->d_fprims, fprims.data(), fprims.size()));
+    UP(dev_upload(&s->d_ref_anc, ref_anc.data(), ref_anc.size()));
+    UP(dev_upload(&s->d_ref_depth, ref_depth.data(), ref_depth.size()));
+    UP(dev_upload(&s->d_leaf_anc, leaf_anc.data(), leaf_anc.size()));
+  }
   UP(dev_upload(&s->d_prims, prims.data(), (size_t)np));
   UP(dev_upload(&s->d_prim_ids, pids.data(), (size_t)np));
   UP(dev_upload(&s->d_mats, mats.data(), mats.size()));
@@ -339,7 +444,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
 
   KScene &k = s->ks;
-  k.nodes = s->d_nodes32; k.prims = s->d_prims; k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
+  k.nodes = s->d_nodes32; k.prims = s->d_prims; k.tprims = s->d_prims;
+  k.ref_nodes64 = s->d_nodes64; k.ref_anc = s->d_ref_anc; k.ref_depth = s->d_ref_depth; k.leaf_anc = s->d_leaf_anc;
+  k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
   k.plane_boxes = s->d_plane_boxes; k.tri_normals = s->d_tri_normals; k.sky = s->d_sky;
   k.root_ref = is_leaf(0) ? d->node_child[0] : 0;
   k.n_lights = d->n_lights;
@@ -377,7 +484,7 @@ static int check_frame(const rt_scene *s, const rt_camera *cam, const rt_params 
     return fail(RT_ERR_INVALID, "bad image/raytracer settings");
   if ((long long)p->width * p->height >= (1LL << 31)) return fail(RT_ERR_UNSUPPORTED, "image too large");
   if (p->rr_start_bounce != 0) return fail(RT_ERR_UNSUPPORTED, "Russian roulette is not in the reference (Config.hs:57) and not implemented");
-  if (p->box_precision != 0 && p->box_precision != 1) return fail(RT_ERR_INVALID, "box_precision must be 0 or 1");
+  if (p->box_precision < 0 || p->box_precision > 2) return fail(RT_ERR_INVALID, "box_precision must be 0, 1 or 2");
   return RT_OK;
 }
 
@@ -397,9 +504,11 @@ static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
 // One frame (or one rank's share of it) = one or more launches of k_render_tiles + k_resolve.  A launch covers a
 // range of the rank's tiles whose per-path radiance fits the sample buffer; normally that is the whole frame
 // (1080p x 100 spp: 5 GB of 288 GB).  The split never changes a result: k_resolve sums in sample order.
-template <typename BT, bool STATS>
+template <typename BT, bool STATS, bool FAST>
 static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   KFrame fr = fr_in;
+  const int n_internal = FAST ? s->f_internal : s->n_internal;
+  fr.stack_depth = std::max(1, FAST ? s->f_depth : s->depth) + 1;
   // One workgroup per CU, RT_MIN_WAVES waves per SIMD; deep trees (long per-lane stacks) get fewer waves so that the
   // stacks still fit the CU's LDS.  What is left of 160 KB caches the top BVH levels.
   // per wave: RT_STACK_LDS stack rows + the record's hot rows; deeper stack entries overflow to global memory
@@ -417,12 +526,12 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
     int cap = RT_TOP_NODES_MAX;
     const char *env = getenv("RT_TOP_NODES");               // experiment knob
     if (env) cap = atoi(env);
-    fr.top_nodes = (int)std::min<size_t>(std::min<size_t>(room, (size_t)cap), (size_t)s->n_internal);
+    fr.top_nodes = (int)std::min<size_t>(std::min<size_t>(room, (size_t)cap), (size_t)n_internal);
   }
   size_t lds = lds_waves + (size_t)fr.top_nodes * sizeof(DNode<float>);
   if (const char *pad = getenv("RT_LDS_BYTES")) lds = std::max(lds, (size_t)atol(pad));   // experiment knob: caps blocks per CU
   if (lds > lds_cu) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
-  auto kern = k_render_tiles<BT, STATS>;
+  auto kern = k_render_tiles<BT, STATS, FAST>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
@@ -466,6 +575,7 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   if (STATS) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
   KScene ks = s->ks;
   if (sizeof(BT) == 8) ks.nodes = s->d_nodes64;
+  if (FAST) { ks.nodes = s->d_fnodes32; ks.tprims = s->d_fprims; ks.root_ref = s->f_root_ref; }
   for (size_t t0 = 0; t0 < (size_t)fr.n_tiles; t0 += tpp) {
     fr.tile_begin = (int32_t)t0;
     fr.tile_end = (int32_t)std::min<size_t>((size_t)fr.n_tiles, t0 + tpp);
@@ -510,14 +620,11 @@ static int launch_render(rt_scene *s, const rt_camera *cam, const rt_params *p, 
   fr.packed = packed ? 1 : 0;
   fr.out_color = d_color; fr.out_radiance = d_radiance; fr.out_primid = d_primid;
   fr.tile_counter = s->d_counter; fr.stats = s->d_stats;
-  fr.stack_depth = std::max(1, s->depth) + 1;
   if (fr.n_tiles == 0) return RT_OK;
-  if (p->box_precision == 1 && !s->d_nodes64) {
-    if ((rc = dev_upload(&s->d_nodes64, s->h_nodes64.data(), s->h_nodes64.size()))) return rc;
-  }
   const bool st = p->collect_stats != 0;
-  if (p->box_precision == 1) return st ? launch_kernel<double, true>(s, fr, stream) : launch_kernel<double, false>(s, fr, stream);
-  return st ? launch_kernel<float, true>(s, fr, stream) : launch_kernel<float, false>(s, fr, stream);
+  if (p->box_precision == 1) return st ? launch_kernel<double, true, false>(s, fr, stream) : launch_kernel<double, false, false>(s, fr, stream);
+  if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, fr, stream) : launch_kernel<float, false, true>(s, fr, stream);
+  return st ? launch_kernel<float, true, false>(s, fr, stream) : launch_kernel<float, false, false>(s, fr, stream);
 }
 
 static int read_stats(rt_scene *s, rt_stats *st) {
