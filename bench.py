@@ -74,10 +74,16 @@ def main():
     bufs = [torch.empty_like(packed) for _ in range(world)] if (rank == 0 and world > 1) else None
     stream = torch.cuda.current_stream().cuda_stream
 
-    # ---- untimed counting pass: rays / nodes / primitive tests of this rank's share (deterministic per seed).
-    # box_precision=1 runs the reference's FP64 slab test without speculation, i.e. it visits exactly the nodes the
-    # reference visits: those counts are the ALGORITHMIC work (the timed kernel visits ~2 % more nodes speculatively).
-    st = scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream, collect_stats=1, box_precision=1)
+    # ---- untimed counting passes: rays / nodes / primitive tests of this rank's share (deterministic per seed).
+    # (1) box_precision=0, the mode that is timed: what the kernel's own traversal (its SAH tree) fetches.  These are the
+    #     algorithmic bytes of the algorithm that runs, the numerator of roofline.achieved.
+    # (2) box_precision=1 walks the reference's tree with its FP64 slab test, i.e. exactly the reference's node visits:
+    #     SURVEY 8(d)'s per-ray figure for the reference algorithm, reported beside it.
+    st_ref = scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream, collect_stats=1, box_precision=1)
+    torch.cuda.synchronize()
+    ref_work = (st_ref.nodes_visited, st_ref.tri_tests + st_ref.sphere_tests + st_ref.plane_tests, st_ref.shaded_hits,
+                st_ref.rays_closest + st_ref.rays_shadow)
+    st = scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream, collect_stats=1, box_precision=0)
     torch.cuda.synchronize()
     cnt = torch.tensor([st.rays_closest, st.rays_shadow, st.nodes_visited, st.tri_tests, st.sphere_tests, st.plane_tests,
                         st.shaded_hits, st.paths], dtype=torch.int64, device=dev)
@@ -161,18 +167,24 @@ def main():
                        "end_to_end_s": round(t_setup + ms_per_step * 1e-3 + t_ppm, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_render_tiles<float,false>", "kernel_ms": round(kernel_ms, 3), "launches": k_n,
+                         "kernel": "k_render_tiles<float,false,true>", "kernel_ms": round(kernel_ms, 3), "launches": k_n,
                          "render_plus_resolve_ms": round(render_ms, 3),
                          "algorithmic_bytes_per_launch": my_alg_bytes,
                          "bytes_per_ray": round(my_alg_bytes / max(1, mine[0] + mine[1]), 1),
                          "nodes_per_ray": round(mine[2] / max(1, mine[0] + mine[1]), 2),
                          "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / max(1, mine[0] + mine[1]), 2),
+                         "reference_algorithm": {
+                             "note": "the same rays through the reference's median-split tree (box_precision=1): SURVEY 8(d)'s figure",
+                             "nodes_per_ray": round(ref_work[0] / max(1, ref_work[3]), 2),
+                             "prim_tests_per_ray": round(ref_work[1] / max(1, ref_work[3]), 2),
+                             "bytes_per_ray": round((NODE_BYTES * ref_work[0] + PRIM_BYTES * ref_work[1] + MAT_BYTES * ref_work[2]) / max(1, ref_work[3]), 1)},
                          "pmc": pmc,
                          "scene_bytes": NODE_BYTES * (scene.bvh.n_nodes - scene.bvh.n_leaves) + PRIM_BYTES * scene.bvh.n_prims,
-                         "note": "algorithmic bytes are mostly served on chip (LDS / L1 / L2, Infinity Cache): frac can exceed 1 "
-                                 "when the scene fits the caches; `traffic` is the measured HBM-side volume per launch "
-                                 "(rocprofv3 FETCH_SIZE/WRITE_SIZE, committed under profiles/). The kernel is latency bound, "
-                                 "see DESIGN.md section 7"},
+                         "note": "algorithmic bytes = what the kernel's own traversal fetches (64 B per node visit, 80 B per primitive "
+                                 "test, 64 B per shaded hit); they are mostly served on chip (LDS / L1 / L2, Infinity Cache) when the "
+                                 "scene fits the caches, so frac is not an HBM utilisation; `traffic` is the measured HBM-side volume "
+                                 "per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, committed under profiles/). The kernel is VALU-issue "
+                                 "bound, see DESIGN.md section 7"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_threads)

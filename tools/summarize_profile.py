@@ -75,7 +75,7 @@ def main():
         out[k] = {"launch": meta.get(k, {}), "counters_per_launch": per, "derived": der}
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 
-    main_k = [k for k in out if "false" in k]
+    main_k = [k for k in out if "<float, false" in k]     # the timed variant: FP32 boxes, no STATS counters
     lines = [f"# rocprofv3 summary {tag} — `bench.py` ({workload_key})", "",
              "Source: `tools/profile.sh` on one MI355X; one rocprofv3 run per pass (kernel trace, then PMC passes).", "",
              "## kernel-trace --stats", "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
