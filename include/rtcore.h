@@ -180,6 +180,15 @@ int  rt_abi_version(void);
 int  rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
 
+/* Diagnostic (no counterpart in the reference; needs no GPU): the render core's OWN acceleration structure, the
+ * binned-SAH tree rt_scene_create builds over the scene's primitives and the kernels traverse when box_precision = 0
+ * (the reference's tree still settles exact ties and bounds planes).  boxes: 6 doubles per primitive.
+ * Outputs are caller-allocated for the worst case of 2*n_prims node indices: node_bounds[12*n_prims],
+ * node_child[4*n_prims] (internal: left, right; leaf: -1 - first_slot, count; unused index: 0, 0), order[n_prims]
+ * (slot -> primitive).  Root = node 0.  The result does not depend on n_threads. */
+int  rt_fast_bvh_build(int32_t n_prims, const double *boxes, int32_t max_leaf, int32_t n_threads,
+                       double *node_bounds, int32_t *node_child, int32_t *order, int32_t *depth);
+
 /* One frame, host buffers in and out: the replacement of the worker fan-out. Blocking. */
 int  rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                rt_output *out, rt_stats *stats);

@@ -225,6 +225,33 @@ class GpuScene:
             pass
 
 
+def prim_boxes(kind, data) -> np.ndarray:
+    """The boxes rt_scene_create gives the render core's own tree: triangles padded by 1e-8 (Triangle.hs:24-28),
+    spheres exact (Sphere.hs:20-22).  Planes get the box of their reference leaf there and are not handled here."""
+    kind = np.asarray(kind); data = np.asarray(data, np.float64).reshape(-1, 9)
+    out = np.empty((len(kind), 6))
+    tri = kind == 0
+    v = data[tri].reshape(-1, 3, 3)
+    out[tri, :3] = v.min(axis=1) - 1e-8
+    out[tri, 3:] = v.max(axis=1) + 1e-8
+    sph = kind == 1
+    out[sph, :3] = data[sph, :3] - np.abs(data[sph, 3:4])
+    out[sph, 3:] = data[sph, :3] + np.abs(data[sph, 3:4])
+    if (kind == 2).any():
+        raise ValueError("planes are bounded by their reference leaf: build the scene instead")
+    return out
+
+
+def fast_bvh(boxes, max_leaf=4, n_threads=1):
+    """rt_fast_bvh_build: the render core's own SAH tree over `boxes` (n, 6).  Returns a dict with the COMPACTED tree:
+    node_bounds (m, 6), node_child (m, 2) (leaf: -1 - first_slot, count), order (n,), depth."""
+    boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 6)
+    n = len(boxes)
+    nb = np.zeros((2 * n, 6)); nc = np.zeros((2 * n, 2), np.int32); order = np.zeros(n, np.int32); depth = C.c_int32(0)
+    F.check(F.core().rt_fast_bvh_build(n, _dp(boxes), int(max_leaf), int(n_threads), _dp(nb), _ip(nc), _ip(order), C.byref(depth)))
+    return {"node_bounds": nb, "node_child": nc, "order": order, "depth": depth.value}
+
+
 def tile_list(width, height, rank, world) -> np.ndarray:
     lib = F.core()
     n = F.check(lib.rt_tile_count(width, height, rank, world))

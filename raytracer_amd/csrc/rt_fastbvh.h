@@ -125,7 +125,8 @@ struct Builder {
 }  // namespace fastbvh
 
 // boxes: 6 doubles per primitive (lo.xyz, hi.xyz), finite.  max_leaf >= 1.  n_threads <= 1: serial.
-inline void build_fast_bvh(int n_prims, const double *boxes, int max_leaf, int n_threads, FastBvh &out) {
+// cost_isect: cost of one primitive test in units of one (two-box) node visit.
+inline void build_fast_bvh(int n_prims, const double *boxes, int max_leaf, double cost_isect, int n_threads, FastBvh &out) {
   out.bounds.assign((size_t)12 * n_prims, 0.0);
   out.child.assign((size_t)4 * n_prims, 0);
   out.order.resize(n_prims);
@@ -137,7 +138,7 @@ inline void build_fast_bvh(int n_prims, const double *boxes, int max_leaf, int n
     for (int k = 0; k < 3; ++k) B.cen[3 * (size_t)i + k] = (float)(0.5 * (boxes[6 * (size_t)i + k] + boxes[6 * (size_t)i + 3 + k]));
   B.out = &out;
   B.max_leaf = std::max(1, max_leaf);
-  B.cost_isect = 1.2;   // one FP64 primitive test against one two-box node visit, in kernel instructions
+  B.cost_isect = cost_isect;
   B.cost_trav = 1.0;
   int pd = 0;
   while ((1 << pd) < n_threads) ++pd;

@@ -357,7 +357,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     if (fast_ok) {
       int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
       if (const char *env = getenv("RT_BUILD_THREADS")) nt = std::max(1, atoi(env));
-      build_fast_bvh(np, pbox.data(), 4, nt, fb);
+      int max_leaf = 4;
+      double cost_isect = 1.2;
+      if (const char *env = getenv("RT_FAST_LEAF")) max_leaf = std::max(1, atoi(env));        // experiment knobs
+      if (const char *env = getenv("RT_FAST_CI")) cost_isect = atof(env);
+      build_fast_bvh(np, pbox.data(), max_leaf, cost_isect, nt, fb);
       if (fb.depth > 60) fast_ok = false;
     }
   }
@@ -458,6 +462,20 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   return RT_OK;
 }
 
+
+int rt_fast_bvh_build(int32_t n_prims, const double *boxes, int32_t max_leaf, int32_t n_threads,
+                      double *node_bounds, int32_t *node_child, int32_t *order, int32_t *depth) {
+  if (n_prims <= 0 || !boxes || !node_bounds || !node_child || !order) return fail(RT_ERR_INVALID, "bad fast-tree arguments");
+  for (size_t i = 0; i < (size_t)6 * n_prims; ++i)
+    if (!std::isfinite(boxes[i])) return fail(RT_ERR_INVALID, "non-finite primitive box");
+  FastBvh fb;
+  build_fast_bvh(n_prims, boxes, std::max(1, max_leaf), 1.2, n_threads, fb);
+  std::memcpy(node_bounds, fb.bounds.data(), fb.bounds.size() * sizeof(double));
+  std::memcpy(node_child, fb.child.data(), fb.child.size() * sizeof(int32_t));
+  std::memcpy(order, fb.order.data(), fb.order.size() * sizeof(int32_t));
+  if (depth) *depth = fb.depth;
+  return RT_OK;
+}
 
 int rt_tile_count(int32_t W, int32_t H, int32_t rank, int32_t world) {
   if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad tile query");
