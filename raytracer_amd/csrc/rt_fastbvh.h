@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <future>
+#include <memory>
 #include <vector>
 
 struct FastBvh {
@@ -47,8 +48,9 @@ struct Builder {
   int max_leaf;
   double cost_isect, cost_trav;
   int par_depth;                 // spawn threads for subtrees above this depth
+  int n_threads;
 
-  int bin_of(float c, float lo, float scale) const { return std::min(NBINS - 1, std::max(0, (int)((c - lo) * scale))); }
+  static int bin_of(float c, float lo, float scale, int nb) { return std::min(nb - 1, std::max(0, (int)((c - lo) * scale))); }
 
   int build(int lo, int hi, int base, int depth) {
     int32_t *order = out->order.data();
@@ -68,26 +70,62 @@ struct Builder {
     if (depth < 40) {                      // SAH over NBINS centroid bins per axis; deeper: balanced halves (bounds the stack)
       double best_cost = INFINITY;
       int best_axis = -1, best_bin = -1;
+      // one pass over the primitives fills the bins of all three axes; large nodes are binned by several threads
+      // (bin boxes and counts merge exactly: min / max / integer sums, so the tree does not depend on the thread count)
+      const int nb = n > 48 ? NBINS : 8;      // small nodes: fewer bins (clearing and sweeping them would dominate the build)
+      float clo3[3], scale3[3];
+      bool use[3];
       for (int ax = 0; ax < 3; ++ax) {
-        const float clo = (float)cb.lo[ax], ext = (float)cb.hi[ax] - clo;
-        if (!(ext > 0.0f)) continue;
-        const float scale = (float)NBINS / ext;
-        Box bb[NBINS];
-        int cnt[NBINS];
-        for (int i = 0; i < NBINS; ++i) { bb[i].reset(); cnt[i] = 0; }
-        for (int i = lo; i < hi; ++i) {
-          const int p = order[i], q = bin_of(cen[3 * (size_t)p + ax], clo, scale);
-          bb[q].grow(boxes + 6 * (size_t)p);
-          cnt[q]++;
+        clo3[ax] = (float)cb.lo[ax];
+        const float ext = (float)cb.hi[ax] - clo3[ax];
+        use[ax] = ext > 0.0f;
+        scale3[ax] = use[ax] ? (float)nb / ext : 0.0f;
+      }
+      struct Bins { Box bb[3][NBINS]; int cnt[3][NBINS]; };
+      auto bin_range = [&](int a, int e, Bins &B) {
+        for (int ax = 0; ax < 3; ++ax) for (int i = 0; i < nb; ++i) { B.bb[ax][i].reset(); B.cnt[ax][i] = 0; }
+        for (int i = a; i < e; ++i) {
+          const int p = order[i];
+          const double *pb = boxes + 6 * (size_t)p;
+          for (int ax = 0; ax < 3; ++ax) {
+            if (!use[ax]) continue;
+            const int q = bin_of(cen[3 * (size_t)p + ax], clo3[ax], scale3[ax], nb);
+            B.bb[ax][q].grow(pb);
+            B.cnt[ax][q]++;
+          }
         }
+      };
+      Bins bins_store, *bins = &bins_store;
+      const int chunks = (depth < par_depth && n > 65536) ? std::min(16, std::max(1, n_threads >> depth)) : 1;
+      if (chunks > 1) {
+        std::vector<std::unique_ptr<Bins>> part(chunks);
+        std::vector<std::future<void>> futs;
+        for (int c = 0; c < chunks; ++c) {
+          part[c].reset(new Bins);
+          const int a = lo + (int)((long long)n * c / chunks), e = lo + (int)((long long)n * (c + 1) / chunks);
+          Bins *dst = part[c].get();
+          futs.push_back(std::async(std::launch::async, [&bin_range, a, e, dst]() { bin_range(a, e, *dst); }));
+        }
+        for (auto &f : futs) f.get();
+        *bins = *part[0];
+        for (int c = 1; c < chunks; ++c)
+          for (int ax = 0; ax < 3; ++ax)
+            for (int i = 0; i < nb; ++i) { bins->bb[ax][i].grow(part[c]->bb[ax][i]); bins->cnt[ax][i] += part[c]->cnt[ax][i]; }
+      } else {
+        bin_range(lo, hi, *bins);
+      }
+      for (int ax = 0; ax < 3; ++ax) {
+        if (!use[ax]) continue;
+        const Box *bb = bins->bb[ax];
+        const int *cnt = bins->cnt[ax];
         double r_area[NBINS];
         int r_cnt[NBINS];
         Box acc;
         acc.reset();
         int c = 0;
-        for (int i = NBINS - 1; i > 0; --i) { acc.grow(bb[i]); c += cnt[i]; r_area[i] = c ? acc.area() : 0.0; r_cnt[i] = c; }
+        for (int i = nb - 1; i > 0; --i) { acc.grow(bb[i]); c += cnt[i]; r_area[i] = c ? acc.area() : 0.0; r_cnt[i] = c; }
         acc.reset(); c = 0;
-        for (int i = 0; i + 1 < NBINS; ++i) {
+        for (int i = 0; i + 1 < nb; ++i) {
           acc.grow(bb[i]); c += cnt[i];
           if (c == 0 || r_cnt[i + 1] == 0) continue;
           const double cost = acc.area() * c + r_area[i + 1] * r_cnt[i + 1];
@@ -97,8 +135,8 @@ struct Builder {
       if (best_axis >= 0) {
         const double leaf_cost = cost_isect * n * b.area(), split_cost = cost_trav * b.area() + cost_isect * best_cost;
         if (n <= max_leaf && leaf_cost <= split_cost) return make_leaf();
-        const float clo = (float)cb.lo[best_axis], scale = (float)NBINS / ((float)cb.hi[best_axis] - clo);
-        mid = (int)(std::partition(order + lo, order + hi, [&](int p) { return bin_of(cen[3 * (size_t)p + best_axis], clo, scale) <= best_bin; }) - order);
+        const float clo = clo3[best_axis], scale = scale3[best_axis];
+        mid = (int)(std::partition(order + lo, order + hi, [&](int p) { return bin_of(cen[3 * (size_t)p + best_axis], clo, scale, nb) <= best_bin; }) - order);
       } else if (n <= max_leaf) {
         return make_leaf();                // all centres coincide (duplicates)
       }
@@ -143,5 +181,6 @@ inline void build_fast_bvh(int n_prims, const double *boxes, int max_leaf, doubl
   int pd = 0;
   while ((1 << pd) < n_threads) ++pd;
   B.par_depth = n_threads > 1 ? pd + 2 : 0;
+  B.n_threads = std::max(1, n_threads);
   out.depth = B.build(0, n_prims, 0, 0);
 }
