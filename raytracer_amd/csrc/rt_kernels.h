@@ -55,7 +55,9 @@ struct KFrame {
   // one launch covers the local tiles [tile_begin, tile_end) of this rank's list: items = (tile, position, sample)
   int32_t tile_begin, tile_end;
   uint32_t n_items;            // (tile_end - tile_begin) * 64 * spp
+  uint32_t chunk;              // items a wave takes from the counter at a time (a multiple of 64, set per launch)
   double *samples;             // [n_items][3] radiance of every path of this launch, summed per pixel by k_resolve
+  unsigned long long *dbg;     // experiment builds (-DRT_TIMERS) only: 4 words per wave, see the end of k_render_tiles
 };
 
 enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };

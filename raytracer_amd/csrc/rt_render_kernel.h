@@ -3,7 +3,7 @@
 // and the history of the numbers quoted here: DESIGN.md sections 5 and 7.
 //
 // Work items.  A lane is a worker that pulls PATHS: item q <-> (tile of this rank's list, position in the 8x8
-// tile, sample).  A wave takes RT_CHUNK consecutive items at a time from one global atomic counter and hands them to
+// tile, sample).  A wave takes fr.chunk consecutive items at a time from one global atomic counter and hands them to
 // its lanes as they fall idle (refill); consecutive items are consecutive samples of one pixel, so a freshly filled
 // wave traces 64 nearly identical primary rays.  The RNG is keyed by (pixel, sample); the path's radiance goes to
 // samples[q] and k_resolve sums each pixel's samples in sample order (RenderWorker.hs:111-114), so a frame does not
@@ -46,9 +46,6 @@
 #define RT_MARK(name) asm volatile("; RTMARK " name ::: "memory")
 #else
 #define RT_MARK(name) do { } while (0)
-#endif
-#ifndef RT_CHUNK
-#define RT_CHUNK 1024u      // items a wave takes from the global counter at a time (multiple of 64)
 #endif
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 6      // traversal-stack entries kept in LDS; deeper entries (4.6 % of the pushes on C4) go to global memory
@@ -199,6 +196,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   // ---- wave-uniform pool of items [pool_next, pool_end)
   uint32_t pool_next = 0, pool_end = 0;
   bool exhausted = false;
+#ifdef RT_TIMERS
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_texh = 0;
+  uint32_t dbg_chunks = 0;
+#endif
 
 #define RT_BEGIN_QUERY(q_tmax)                                                     \
   do {                                                                             \
@@ -226,14 +228,17 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   } while (0)
 
   // Gives every idle lane its next item.  All lanes of the wave run this (uniform control flow).
-  // item q of this launch -> local tile q / (64 spp), position in the 8x8 tile (q / spp) % 64, sample q % spp.
-  // The chunk start is decomposed once per chunk (wave-uniform); a lane's item then needs only small divisions.
-  uint32_t pool_base = 0, pool_lt0 = 0, pool_pos0 = 0, pool_s0 = 0;
+  // A chunk is fr.chunk CONSECUTIVE items (samples of neighbouring pixels keep a wave's rays in the same part of the
+  // tree: mixing image regions inside a chunk cost 5 % of throughput).  Its size is set per launch from the items each
+  // resident wave will process: the few hundred chunks under the blob (sliver triangles around its pole, five bounces in
+  // the gap above the pedestal) cost 9x the median, and with 1024-item chunks whichever waves held them last finished
+  // 6.5 ms after the others whatever the launch size - 13.1 instead of 6.4 ms for a rank's 1/8 share of C4.
   auto refill = [&]() {
     RT_COLD_ARGS();
-    const uint32_t per_tile = 64u * (uint32_t)fr.spp;
+    const uint32_t n_groups = fr.n_items >> 6;             // n_items is a multiple of 64 (64 slots per tile)
+    const uint32_t chunk = fr.chunk;
     const float rcp_spp = 1.0f / (float)fr.spp, rcp_tx = 1.0f / (float)fr.tiles_x;
-    const bool small_div = fr.spp < (1 << 22) && (uint32_t)fr.tiles_x * (uint32_t)((fr.H + 7) / 8) < (1u << 24);
+    const bool small_div = fr.spp < (1 << 18) && n_groups < (1u << 24) && (uint32_t)fr.tiles_x * (uint32_t)((fr.H + 7) / 8) < (1u << 24);
     for (;;) {
       const unsigned long long need = __ballot(cur == CUR_IDLE);
       if (need == 0ull) break;
@@ -241,25 +246,28 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(fr.tile_counter, 1u);
         c = __builtin_amdgcn_readfirstlane(c);
-        if ((unsigned long long)c * RT_CHUNK >= (unsigned long long)fr.n_items) { exhausted = true; break; }
-        pool_next = c * RT_CHUNK;
-        pool_end = fr.n_items - pool_next < RT_CHUNK ? fr.n_items : pool_next + RT_CHUNK;
-        pool_base = pool_next;
-        pool_lt0 = pool_base / per_tile;
-        const uint32_t rem0 = pool_base - pool_lt0 * per_tile;
-        pool_pos0 = rem0 / (uint32_t)fr.spp;
-        pool_s0 = rem0 - pool_pos0 * (uint32_t)fr.spp;
+#ifdef RT_TIMERS
+        if ((unsigned long long)c * chunk >= (unsigned long long)fr.n_items) dbg_texh = wall_clock64(); else ++dbg_chunks;
+        if (fr.dbg && lane == 0 && c < 262144u) {            // per chunk: who took it and when
+          unsigned long long *e_ = fr.dbg + 4 * (size_t)gridDim.x * (blockDim.x >> 6) + 2 * (size_t)c;
+          e_[0] = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e_[1] = wall_clock64();
+        }
+#endif
+        if ((unsigned long long)c * chunk >= (unsigned long long)fr.n_items) { exhausted = true; break; }
+        pool_next = c * chunk;
+        pool_end = fr.n_items - pool_next < chunk ? fr.n_items : pool_next + chunk;
       }
       const uint32_t avail = pool_end - pool_next;
       const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));   // my index among the idle lanes
       const uint32_t n_need = (uint32_t)__popcll(need);
+      const uint32_t q = pool_next + rank;
+      const uint32_t g2 = q >> 6, off = q & 63u;           // group of 64 items, offset in the group
       if (cur == CUR_IDLE && rank < avail) {
-        const uint32_t q = pool_next + rank;
-        const uint32_t t_ = pool_s0 + (q - pool_base);     // < spp + RT_CHUNK
-        const uint32_t dpos = small_div ? fastdiv24(t_, (uint32_t)fr.spp, rcp_spp) : t_ / (uint32_t)fr.spp;
-        const uint32_t smp = t_ - dpos * (uint32_t)fr.spp;
-        const uint32_t p_ = pool_pos0 + dpos;
-        const uint32_t lt = pool_lt0 + (p_ >> 6), pos = p_ & 63u;
+        // item q -> local tile q / (64 spp), position in the 8x8 tile (q / spp) % 64, sample q % spp
+        const uint32_t lt = small_div ? fastdiv24(g2, (uint32_t)fr.spp, rcp_spp) : g2 / (uint32_t)fr.spp;
+        const uint32_t rem = (g2 - lt * (uint32_t)fr.spp) * 64u + off;          // < 64 spp
+        const uint32_t pos = small_div ? fastdiv24(rem, (uint32_t)fr.spp, rcp_spp) : rem / (uint32_t)fr.spp;
+        const uint32_t smp = rem - pos * (uint32_t)fr.spp;
         const uint32_t gt = (uint32_t)fr.tile_begin + lt;  // index into this rank's tile list
         const uint32_t tile = fr.tiles ? (uint32_t)fr.tiles[gt] : gt;
         const uint32_t trow = small_div ? fastdiv24(tile, (uint32_t)fr.tiles_x, rcp_tx) : tile / (uint32_t)fr.tiles_x;
@@ -288,8 +296,13 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
     }
   };
 
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = STATS ? clock64() : 0ull;   // vote, node, prim, shade, refill
-#define RT_TICK(k) do { if (STATS) { const unsigned long long n_ = clock64(); tacc[k] += n_ - tlast; tlast = n_; } } while (0)
+#ifdef RT_TIMERS          // experiment build: per-body wall time in the TIMED kernel variant (no counters, no extra spills)
+  constexpr bool TIMERS = true;
+#else
+  constexpr bool TIMERS = STATS;
+#endif
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = TIMERS ? clock64() : 0ull;   // vote, node, prim, shade, refill
+#define RT_TICK(k) do { if (TIMERS) { const unsigned long long n_ = clock64(); tacc[k] += n_ - tlast; tlast = n_; } } while (0)
   for (;;) {
     if (!exhausted && __popcll(__ballot(cur == CUR_IDLE)) >= RT_REFILL_MIN) {   // all 64 idle at the start
       RT_TICK(0);
@@ -577,9 +590,15 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 #undef RT_BEGIN_QUERY
 #undef RT_POP2
 
-  if (STATS && lane == 0) {
+  if (TIMERS && lane == 0) {
     for (int k = 0; k < 5; ++k) atomicAdd(fr.stats + STAT_T_VOTE + k, tacc[k]);
   }
+#ifdef RT_TIMERS
+  if (fr.dbg && lane == 0) {                               // per wave: start, pool exhausted, end (100 MHz wall clock), chunks taken
+    unsigned long long *d_ = fr.dbg + 4 * ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    d_[0] = dbg_t0; d_[1] = dbg_texh; d_[2] = wall_clock64(); d_[3] = dbg_chunks;
+  }
+#endif
   if (STATS) {
 #pragma unroll
     for (int i = 0; i < STAT_T_VOTE; ++i) {

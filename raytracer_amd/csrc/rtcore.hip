@@ -16,6 +16,9 @@
 #ifndef RT_TOP_NODES_MAX
 #define RT_TOP_NODES_MAX 1023
 #endif
+#ifndef RT_CHUNKS_PER_WAVE
+#define RT_CHUNKS_PER_WAVE 25
+#endif
 #include "rt_kernels.h"
 #include "rt_fastbvh.h"
 #include <thread>
@@ -599,6 +602,14 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
     fr.tile_end = (int32_t)std::min<size_t>((size_t)fr.n_tiles, t0 + tpp);
     const size_t slots = (size_t)(fr.tile_end - fr.tile_begin) * 64;
     fr.n_items = (uint32_t)(slots * fr.spp);
+    // chunk: at most 1/25 of what one resident wave will process, a power of two in [64, 512] (see refill in the kernel)
+    {
+      const size_t per_wave = (size_t)fr.n_items / ((size_t)grid_max * wpb);
+      uint32_t ch = 64;
+      while (ch < 512 && (size_t)ch * 2 * RT_CHUNKS_PER_WAVE <= per_wave) ch *= 2;
+      if (const char *env = getenv("RT_CHUNK_ITEMS")) ch = (uint32_t)std::max(64, (atoi(env) / 64) * 64);   // experiment knob
+      fr.chunk = ch;
+    }
     const size_t want = ((size_t)fr.n_items / 64 + wpb - 1) / wpb;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)grid_max));
     HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
@@ -611,8 +622,22 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
       }
       HIP_TRY(hipEventRecord(s->kt_events[2 * s->kt_pending], stream));
     }
+#ifdef RT_TIMERS
+    static unsigned long long *d_dbg = nullptr;            // experiment build: per-wave timeline, dumped to $RT_WAVE_DUMP after each launch
+    const char *dump = getenv("RT_WAVE_DUMP");
+    if (dump && !d_dbg) HIP_TRY(hipMalloc((void **)&d_dbg, ((size_t)g_ctx.n_cu * 64 * 4 + 2 * 262144) * sizeof(unsigned long long)));
+    fr.dbg = dump ? d_dbg : nullptr;
+    if (dump) HIP_TRY(hipMemsetAsync(d_dbg, 0, ((size_t)grid * wpb * 4 + 2 * 262144) * sizeof(unsigned long long), stream));
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, ks, fr);
     HIP_TRY(hipGetLastError());
+#ifdef RT_TIMERS
+    if (dump) {
+      std::vector<unsigned long long> h((size_t)grid * wpb * 4 + 2 * 262144);
+      HIP_TRY(hipMemcpy(h.data(), d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE *f = fopen(dump, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), f); fclose(f); }
+    }
+#endif
     if (timed) { HIP_TRY(hipEventRecord(s->kt_events[2 * s->kt_pending + 1], stream)); ++s->kt_pending; }
     hipLaunchKernelGGL(k_resolve, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, fr);
     HIP_TRY(hipGetLastError());
@@ -639,7 +664,12 @@ static int launch_render(rt_scene *s, const rt_camera *cam, const rt_params *p, 
   fr.out_color = d_color; fr.out_radiance = d_radiance; fr.out_primid = d_primid;
   fr.tile_counter = s->d_counter; fr.stats = s->d_stats;
   if (fr.n_tiles == 0) return RT_OK;
+#ifdef RT_TIMERS
+  const bool st = false;                                    // experiment build: collect_stats times the bodies of the TIMED variant
+  if (p->collect_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
+#else
   const bool st = p->collect_stats != 0;
+#endif
   if (p->box_precision == 1) return st ? launch_kernel<double, true, false>(s, fr, stream) : launch_kernel<double, false, false>(s, fr, stream);
   if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, fr, stream) : launch_kernel<float, false, true>(s, fr, stream);
   return st ? launch_kernel<float, true, false>(s, fr, stream) : launch_kernel<float, false, false>(s, fr, stream);

@@ -7,7 +7,7 @@ w, h, spp = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1920, 108
 spec = scenes.c4_blob63k(width=w, height=h, spp=spp)
 g = api.GpuScene(spec, n_threads=8)
 res, st = g.render(want=("color",), collect_stats=1)
-rays = st.rays_closest + st.rays_shadow
+rays = max(1, st.rays_closest + st.rays_shadow)      # 0 with the timers-only build (-DRT_TIMERS): only the time split is meaningful
 print(f"rays {rays} closest {st.rays_closest} shadow {st.rays_shadow} shaded {st.shaded_hits} ms {st.ms_render:.2f}")
 print(f"NODE : {st.sched_node_steps} wave-steps, {st.nodes_visited} lane-steps, {st.nodes_visited / max(1, st.sched_node_steps):.1f} lanes/step, {st.nodes_visited / rays:.2f} per ray")
 pt = st.tri_tests + st.sphere_tests + st.plane_tests
@@ -19,5 +19,6 @@ print(f"live lanes per trip: {st.sched_live_lanes / max(1, steps):.1f} of 64")
 print(f"node visits served from LDS: {st.top_node_hits / max(1, st.nodes_visited):.3f}")
 tot = st.cyc_vote + st.cyc_node + st.cyc_prim + st.cyc_shade + st.cyc_refill
 if tot:
+    steps = max(1, steps)
     for n, c, k in (("vote", st.cyc_vote, steps), ("node", st.cyc_node, st.sched_node_steps), ("prim", st.cyc_prim, st.sched_prim_steps), ("shade", st.cyc_shade, st.sched_shade_steps), ("refill", st.cyc_refill, st.sched_shade_steps)):
         print(f"time in {n:6s}: {100 * c / tot:5.1f} %   {c / max(1, k):8.0f} ticks per trip")
