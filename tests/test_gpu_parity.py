@@ -46,7 +46,7 @@ def check_stochastic(res, ref, frac=0.999, rmse=2e-3):
     assert e <= rmse, f"mean-image RMSE {e:.3e}"
 
 
-@pytest.mark.parametrize("box_precision", [0, 1])
+@pytest.mark.parametrize("box_precision", [0, 1, 2])     # own SAH tree / reference tree, exact FP64 slab test / reference tree, FP32 boxes
 def test_c1_deterministic(need_gpu, box_precision):
     spec = scenes.c1_testing(width=640, height=360)          # C1: AA off, maxBounces 1 -> deterministic
     res, ref, _ = render_both(spec, box_precision=box_precision)
@@ -87,15 +87,29 @@ def test_c4_stochastic_small(need_gpu):
 
 
 def test_fp32_boxes_equal_fp64_boxes(need_gpu):
-    # the conservative FP32 box path must visit a superset of the exact FP64 path: identical images
+    # the conservative FP32 box paths (own tree: 0, reference tree: 2) must find what the exact FP64 path (1) finds: identical images
     spec = scenes.c3_blob988(width=256, height=144, spp=4)
     g = api.GpuScene(spec)
-    a, _ = g.render(box_precision=0)
     b, _ = g.render(box_precision=1)
+    for mode in (0, 2):
+        a, _ = g.render(box_precision=mode)
+        same = (np.abs(a["radiance"] - b["radiance"]).max(axis=2) <= 1e-9)
+        assert same.mean() >= 0.9995, mode
+        assert (a["prim_id"] == b["prim_id"]).mean() >= 0.9999, mode
     g.close()
-    same = (np.abs(a["radiance"] - b["radiance"]).max(axis=2) <= 1e-9)
-    assert same.mean() >= 0.9995
-    assert (a["prim_id"] == b["prim_id"]).mean() >= 0.9999
+
+
+def test_own_tree_visits_fewer_nodes(need_gpu):
+    # the point of the core's own tree: same rays, same hits, a fraction of the reference tree's traversal work
+    spec = scenes.c4_blob63k(width=192, height=108, spp=2)
+    g = api.GpuScene(spec)
+    a, sa = g.render(collect_stats=1, box_precision=0)
+    b, sb = g.render(collect_stats=1, box_precision=1)
+    g.close()
+    assert np.abs(a["radiance"] - b["radiance"]).max() <= 1e-9 and (a["prim_id"] == b["prim_id"]).all()
+    assert sa.rays_closest == sb.rays_closest and sa.rays_shadow == sb.rays_shadow
+    assert sa.nodes_visited < 0.5 * sb.nodes_visited
+    assert sa.tri_tests < 0.5 * sb.tri_tests
 
 
 @pytest.mark.parametrize("fmt", ["rgbf", "rgb8"])
