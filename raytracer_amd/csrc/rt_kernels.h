@@ -187,13 +187,15 @@ RT_DEV bool box_test(const BoxRay<float> &r, const float *bx, float tmin, float 
 
 template <typename BT> RT_DEV BT tmax_for_boxes(double best_t);
 template <> RT_DEV double tmax_for_boxes<double>(double best_t) { return best_t; }
-template <> RT_DEV float tmax_for_boxes<float>(double best_t) { return __double2float_ru(best_t); }
+// FP32: rounded up and already widened by the slack, so that the pop-time cull needs no multiplication (the slab test
+// then applies the slack twice to this bound: still a superset)
+template <> RT_DEV float tmax_for_boxes<float>(double best_t) { return __double2float_ru(best_t) * RT_SLACK; }
 template <typename BT> RT_DEV BT tmin_for_boxes();
 template <> RT_DEV double tmin_for_boxes<double>() { return RT_TMIN; }
 template <> RT_DEV float tmin_for_boxes<float>() { return 0.00099999f; }
 // pop-time cull: true when a stacked entry distance is provably beyond the closest hit so far
 RT_DEV bool cull_entry(float tenter, double tmaxb) { return (double)tenter > tmaxb; }
-RT_DEV bool cull_entry(float tenter, float tmaxb) { return tenter > tmaxb * RT_SLACK; }
+RT_DEV bool cull_entry(float tenter, float tmaxb) { return tenter > tmaxb; }
 
 // ---------------------------------------------------------------- primitive tests (FP64, reference order of operations)
 RT_DEV bool hit_triangle(const DPrim &P, d3 ro, d3 rd, double tmin, double tmax, double &tout) {

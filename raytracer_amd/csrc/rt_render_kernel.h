@@ -214,7 +214,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   do {                                                                               \
     _Pragma("unroll") for (int a_ = 0; a_ < RT_POPS; ++a_) {                               \
       const int spn_ = sp - 1;                                                       \
-      uint2 e_ = stack[(spn_ < 0 ? 0 : (spn_ < RT_STACK_LDS ? spn_ : RT_STACK_LDS - 1)) * 64]; \
+      /* one unsigned min clamps both ends: an empty stack (-1) or an overflow entry reads the last LDS row, ignored below */ \
+      uint2 e_ = stack[min((uint32_t)spn_, (uint32_t)(RT_STACK_LDS - 1)) * 64u];       \
       if (__ballot((p_) && spn_ >= RT_STACK_LDS) != 0ull) {          /* rare: the entry is in the overflow rows */ \
         if ((p_) && spn_ >= RT_STACK_LDS) e_ = ovf[(spn_ - RT_STACK_LDS) * 64];      \
       }                                                                              \
