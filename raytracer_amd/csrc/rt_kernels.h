@@ -269,18 +269,44 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 #include "rt_render_kernel.h"
 
 // ---------------------------------------------------------------- small helper kernels
-// One thread per pixel slot of the launch: the pixel's samples summed in sample order, mean, tone map, gamma
-// (pixelColor / averageColor, RenderWorker.hs:111-114; toneMap / gammaCorrect, Trace.hs:96-105).
-__global__ void k_resolve(const KFrame fr) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;            // local slot within the launch
-  if (j >= (uint32_t)(fr.tile_end - fr.tile_begin) * 64u) return;
-  const uint32_t gt = (uint32_t)fr.tile_begin + (j >> 6), pos = j & 63u;
+// One wave per 8x8 tile of the launch (64 pixel slots), one lane per pixel: the pixel's samples summed IN SAMPLE ORDER
+// (the reference's foldl', RenderWorker.hs:111-114 - a sequential sum, so no tree reduction), mean, tone map, gamma
+// (toneMap / gammaCorrect, Trace.hs:96-105).  A pixel's samples are spp x 24 contiguous bytes, a tile's 64 pixels one
+// contiguous region: the wave reads it RS_T samples at a time with all lanes on consecutive addresses (three 192-B runs per
+// instruction instead of 64 scattered 8-B reads), stages the sub-block in LDS and each lane then adds its own pixel's run.
+#define RS_T 8                      // samples per staged sub-block
+#define RS_ROW (3 * RS_T + 1)       // doubles per pixel row in LDS (+1: lanes on different banks)
+#define RS_WAVES 4
+__global__ __launch_bounds__(64 * RS_WAVES) void k_resolve(const KFrame fr) {
+  __shared__ double stage[RS_WAVES][64 * RS_ROW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t lt = blockIdx.x * RS_WAVES + wv;                      // local tile within the launch
+  if (lt >= (uint32_t)(fr.tile_end - fr.tile_begin)) return;          // (whole waves leave: no barrier is used)
+  const uint32_t gt = (uint32_t)fr.tile_begin + lt, pos = (uint32_t)lane;
   const int tile = fr.tiles ? fr.tiles[gt] : (int)gt;
   const int px = (tile % fr.tiles_x) * 8 + (int)(pos & 7u), py = (tile / fr.tiles_x) * 8 + (int)(pos >> 3);
-  if (px >= fr.W || py >= fr.H) return;
-  const double *sp = fr.samples + 3 * (size_t)j * (size_t)fr.spp;
+  const double *base = fr.samples + 3 * (size_t)lt * 64 * (size_t)fr.spp;   // this tile's 64 runs of 3 spp doubles
+  double *st = stage[wv];
   double sx = 0.0, sy = 0.0, sz = 0.0;
-  for (int s = 0; s < fr.spp; ++s) { sx += sp[3 * s]; sy += sp[3 * s + 1]; sz += sp[3 * s + 2]; }
+  for (int s0 = 0; s0 < fr.spp; s0 += RS_T) {
+    const int n = fr.spp - s0 < RS_T ? fr.spp - s0 : RS_T, n3 = 3 * n;
+    {                                                                  // lanes 0..47: (pixel 2 it + lane / 24, element lane % 24): two 192-B runs per instruction
+      const int pp = lane / (3 * RS_T), k = lane - pp * (3 * RS_T);
+      const bool act = pp < 2 && k < n3;
+      const double *src = base + ((size_t)pp * fr.spp + s0) * 3 + k;
+      double *dst = st + pp * RS_ROW + k;
+#pragma unroll 8
+      for (int it = 0; it < 32; ++it)
+        if (act) dst[2 * it * RS_ROW] = src[(size_t)2 * it * fr.spp * 3];
+    }
+    __builtin_amdgcn_wave_barrier();                                   // one wave: LDS writes above are visible to its own lanes after the waitcnt the compiler inserts
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double *r = st + lane * RS_ROW;
+    for (int s = 0; s < n; ++s) { sx += r[3 * s]; sy += r[3 * s + 1]; sz += r[3 * s + 2]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (px >= fr.W || py >= fr.H) return;
   const double inv = 1.0 / (double)fr.spp;
   const d3 avg = mk3(inv * sx, inv * sy, inv * sz);                    // RenderWorker.hs:114
   const size_t o = 3 * (fr.packed ? (size_t)gt * 64 + pos : (size_t)py * fr.W + px);

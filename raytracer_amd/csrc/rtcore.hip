@@ -639,7 +639,7 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
     }
 #endif
     if (timed) { HIP_TRY(hipEventRecord(s->kt_events[2 * s->kt_pending + 1], stream)); ++s->kt_pending; }
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, fr);
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)((slots / 64 + RS_WAVES - 1) / RS_WAVES)), dim3(64 * RS_WAVES), 0, stream, fr);
     HIP_TRY(hipGetLastError());
   }
   return RT_OK;
