@@ -85,8 +85,11 @@ def main():
                 st_ref.rays_closest + st_ref.rays_shadow)
     st = scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream, collect_stats=1, box_precision=0)
     torch.cuda.synchronize()
+    # The reference algorithm makes one shadow query per light and hit; the timed mode does not trace those whose light term
+    # is zero either way (surface facing away from the light, rays_shadow_culled).  `value` counts only the queries that
+    # were TRAVERSED; the reference's count (what the CPU baseline is measured on) is reported beside it.
     cnt = torch.tensor([st.rays_closest, st.rays_shadow, st.nodes_visited, st.tri_tests, st.sphere_tests, st.plane_tests,
-                        st.shaded_hits, st.paths], dtype=torch.int64, device=dev)
+                        st.shaded_hits, st.paths, st.rays_shadow_culled], dtype=torch.int64, device=dev)
     my_cnt = cnt.clone()
     if world > 1:
         dist.all_reduce(cnt)
@@ -161,7 +164,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{spec.name}: {spec.n_triangles()} triangles, {W}x{H}, {spec.spp} spp, maxBounces {spec.max_bounces}, "
                                    f"leafThreshold {spec.leaf_threshold}, bvhMaxDepth {spec.bvh_max_depth}, 1 point light",
-                       "parallelism": f"tiles{world}", "rays_per_frame": rays_total, "paths_per_frame": tot[7],
+                       "parallelism": f"tiles{world}", "rays_per_frame": rays_total, "rays_shadow_culled": tot[8], "reference_rays_per_frame": rays_total + tot[8],
+                       "paths_per_frame": tot[7],
                        "frame_time_s": round(ms_per_step * 1e-3, 5), "kernel_ms": round(kernel_ms_max, 3),
                        "setup_s": round(t_setup, 3), "d2h_plus_ppm_text_s": round(t_ppm, 3),
                        "end_to_end_s": round(t_setup + ms_per_step * 1e-3 + t_ppm, 3)},

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 /* ---- status codes (error convention replaces `error`/exitFailure, app/Main.hs:24-26) */
 #define RT_OK                 0
@@ -166,6 +166,8 @@ typedef struct rt_stats {
   uint64_t top_node_hits;      /* node visits served by the LDS copy of the top BVH levels */
   uint64_t sched_live_lanes;   /* sum over all trips of the lanes that still had work */
   uint64_t cyc_vote, cyc_node, cyc_prim, cyc_shade, cyc_refill;   /* shader-clock ticks summed over waves, per body */
+  uint64_t rays_shadow_culled; /* box_precision = 0 only: shadow queries of the reference NOT traced (and not in rays_shadow)
+                                  because the surface faces away from the light: their term is max(0, n.l) = 0 either way */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -60,7 +60,7 @@ struct KFrame {
   unsigned long long *dbg;     // experiment builds (-DRT_TIMERS) only: 4 words per wave, see the end of k_render_tiles
 };
 
-enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
+enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_SHADOW_CULLED, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
 
 // cold code (once per path, not per traversal step).  Inlined: taking KScene/KFrame by reference out of line cost more
 // scratch than it saved registers; only the libm-heavy leaves (sky_uv, pow_gamma) are real calls.

@@ -412,14 +412,23 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         }
         if (!need_scatter && !need_finish) {                 // shadow ray towards light li (Light.hs:26-30, 39-42)
           RT_COLD_ARGS();
-          const DLight L = sc.lights[li];
-          if (L.kind == RT_LIGHT_POINT) {
-            const d3 tl = ld3(L.vec) - ro;
-            rd = normalize3(tl);
-            q_tmax = sqrt(dot3(tl, tl)) - 0.01;
-          } else {
-            rd = normalize3(-1.0 * ld3(L.vec));
-            q_tmax = RT_TMAX;
+          // FAST: a light the surface faces away from adds max(0, n.l) * ... = 0 whether or not it is visible
+          // (Light.hs:36-38, 48-49), so its shadow query is not traced; the next light, or the bounce, follows in this trip.
+          d3 lnormal = mk3(0, 0, 0);
+          if (FAST) lnormal = hit_tri ? ((hitp & HITP_FRONT) ? tn2 : neg3(tn2)) : normalize3(nrm);   // as in the light term above
+          for (;;) {
+            const DLight L = sc.lights[li];
+            if (L.kind == RT_LIGHT_POINT) {
+              const d3 tl = ld3(L.vec) - ro;
+              rd = normalize3(tl);
+              q_tmax = sqrt(dot3(tl, tl)) - 0.01;
+            } else {
+              rd = normalize3(-1.0 * ld3(L.vec));
+              q_tmax = RT_TMAX;
+            }
+            if (!FAST || dot3(lnormal, rd) > 0.0) break;
+            if (STATS) st[STAT_SHADOW_CULLED]++;
+            if (--li < 0) { need_scatter = true; q_tmax = RT_TMAX; break; }   // the bounce ray follows in this trip
           }
         }
         if (need_scatter) {                                  // Trace.hs:27-76

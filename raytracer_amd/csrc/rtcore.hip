@@ -683,6 +683,7 @@ static int read_stats(rt_scene *s, rt_stats *st) {
   st->sched_node_steps = h[STAT_IT_NODE] / 64; st->sched_prim_steps = h[STAT_IT_PRIM] / 64; st->sched_shade_steps = h[STAT_IT_SHADE] / 64;
   st->sched_live_lanes = h[STAT_LIVE];
   st->top_node_hits = h[STAT_TOPHIT];
+  st->rays_shadow_culled = h[STAT_SHADOW_CULLED];
   st->cyc_vote = h[STAT_T_VOTE]; st->cyc_node = h[STAT_T_NODE]; st->cyc_prim = h[STAT_T_PRIM]; st->cyc_shade = h[STAT_T_SHADE]; st->cyc_refill = h[STAT_T_REFILL];
   return RT_OK;
 }

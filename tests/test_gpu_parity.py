@@ -107,7 +107,8 @@ def test_own_tree_visits_fewer_nodes(need_gpu):
     b, sb = g.render(collect_stats=1, box_precision=1)
     g.close()
     assert np.abs(a["radiance"] - b["radiance"]).max() <= 1e-9 and (a["prim_id"] == b["prim_id"]).all()
-    assert sa.rays_closest == sb.rays_closest and sa.rays_shadow == sb.rays_shadow
+    assert sa.rays_closest == sb.rays_closest and sa.rays_shadow + sa.rays_shadow_culled == sb.rays_shadow
+    assert 0 < sa.rays_shadow_culled < sb.rays_shadow and sb.rays_shadow_culled == 0   # lights behind the surface are not traced (mode 0 only)
     assert sa.nodes_visited < 0.5 * sb.nodes_visited
     assert sa.tri_tests < 0.5 * sb.tri_tests
 
