@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -11,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #ifndef RT_TOP_NODES_MAX
@@ -21,7 +23,6 @@
 #endif
 #include "rt_kernels.h"
 #include "rt_fastbvh.h"
-#include <thread>
 
 namespace {
 
@@ -55,6 +56,20 @@ int ensure_init() {
 
 float f32_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
 float f32_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
+
+// f(begin, end) over [0, n) in contiguous pieces on up to n_threads host threads (set-up loops over millions of primitives)
+template <typename F> void parallel_for(size_t n, int n_threads, F f) {
+  const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_threads), n / 16384));
+  if (pieces == 1) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < pieces; ++k) th.emplace_back([=]() { f(n * k / pieces, n * (k + 1) / pieces); });
+  for (auto &t : th) t.join();
+}
+int host_threads() {
+  int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char *env = getenv("RT_BUILD_THREADS")) nt = std::max(1, atoi(env));
+  return nt;
+}
 
 template <typename T> int dev_upload(T **dst, const T *src, size_t n) {
   *dst = nullptr;
@@ -163,6 +178,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   if (d->sky_format < RT_SKY_NONE || d->sky_format > RT_SKY_RGBF) return fail(RT_ERR_INVALID, "bad sky format");
 
   const int nn = d->n_nodes, np = d->n_prims;
+  const bool dbg_t = getenv("RT_DEBUG") != nullptr;          // RT_DEBUG: where the set-up time goes
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "rtcore: scene_create %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // ---- validate the tree (every kernel index is checked here, on the host) and order the internal nodes:
   //      the top levels breadth-first (they are the ones every ray touches), the subtrees below depth-first.
   std::vector<int> level(nn, -1), dev_index(nn, -1), order;
@@ -216,6 +239,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   }
   if (depth > 60) return fail(RT_ERR_UNSUPPORTED, "BVH depth %d exceeds the traversal stack limit (60)", depth);
 
+  lap("validate + order ref nodes");
   auto *s = new rt_scene();
   s->device = g_ctx.device;
   s->depth = depth;
@@ -239,7 +263,13 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     for (int i = d->n_materials - 1; i >= 0; --i) if (d->materials[i].id == id) return 1 + i;
     return 0;
   };
-  std::vector<int> mat_cache_id, mat_cache_ix;
+  // material id -> dense index, resolved once per distinct id (a scene has a handful)
+  std::vector<int> mat_ids, mat_ixs;
+  for (int i = 0; i < np; ++i) {
+    const int mid = d->prim_material[i];
+    if (std::find(mat_ids.begin(), mat_ids.end(), mid) == mat_ids.end()) { mat_ids.push_back(mid); mat_ixs.push_back(mat_index(mid)); }
+  }
+  const int n_host_threads = host_threads();
 
   // ---- primitives (leaf order is kept: it decides ties) + the FP64 leaf boxes planes need
   std::vector<DPrim> prims(np);
@@ -254,33 +284,35 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     out[0] = s * v[0]; out[1] = s * v[1]; out[2] = s * v[2];
   };
   double maxabs = 0;
-  for (int i = 0; i < np; ++i) {
-    const double *src = d->prim_data + 9 * (size_t)i;
-    DPrim &P = prims[i];
-    std::memset(&P, 0, sizeof P);
-    int kind = d->prim_kind[i];
-    if (kind < RT_PRIM_TRIANGLE || kind > RT_PRIM_PLANE) { delete s; return fail(RT_ERR_INVALID, "primitive %d has unknown kind %d", i, kind); }
-    if (kind == RT_PRIM_TRIANGLE) {
-      for (int k = 0; k < 3; ++k) {
-        P.d[k] = src[k];
-        P.d[3 + k] = src[3 + k] - src[k];   // e1 = p1 - p0, Triangle.hs:32
-        P.d[6 + k] = src[6 + k] - src[k];   // e2 = p2 - p0, Triangle.hs:33
+  std::atomic<int> bad_prim(-1);
+  parallel_for((size_t)np, n_host_threads, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
+      const double *src = d->prim_data + 9 * i;
+      DPrim &P = prims[i];
+      std::memset(&P, 0, sizeof P);
+      const int kind = d->prim_kind[i];
+      if (kind < RT_PRIM_TRIANGLE || kind > RT_PRIM_PLANE) { bad_prim.store((int)i); return; }
+      if (kind == RT_PRIM_TRIANGLE) {
+        for (int k = 0; k < 3; ++k) {
+          P.d[k] = src[k];
+          P.d[3 + k] = src[3 + k] - src[k];   // e1 = p1 - p0, Triangle.hs:32
+          P.d[6 + k] = src[6 + k] - src[k];   // e2 = p2 - p0, Triangle.hs:33
+        }
+        const double *a = P.d + 3, *b = P.d + 6;
+        const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        normalize_like_device(c, &tri_normals[6 * i]);
+        normalize_like_device(&tri_normals[6 * i], &tri_normals[6 * i + 3]);
+      } else {
+        for (int k = 0; k < 9; ++k) P.d[k] = src[k];
+        if (kind == RT_PRIM_PLANE) P.d[6] = -1.0;
       }
-      const double *a = P.d + 3, *b = P.d + 6;
-      const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-      normalize_like_device(c, &tri_normals[6 * (size_t)i]);
-      normalize_like_device(&tri_normals[6 * (size_t)i], &tri_normals[6 * (size_t)i + 3]);
-    } else {
-      for (int k = 0; k < 9; ++k) P.d[k] = src[k];
-      if (kind == RT_PRIM_PLANE) P.d[6] = -1.0;
+      P.kind = (uint32_t)kind;
+      P.mat = mat_ixs[std::find(mat_ids.begin(), mat_ids.end(), d->prim_material[i]) - mat_ids.begin()];
+      pids[i] = d->prim_id ? d->prim_id[i] : (int32_t)i;
     }
-    P.kind = (uint32_t)kind;
-    int mid = d->prim_material[i], mix = -1;
-    for (size_t k = 0; k < mat_cache_id.size(); ++k) if (mat_cache_id[k] == mid) { mix = mat_cache_ix[k]; break; }
-    if (mix < 0) { mix = mat_index(mid); mat_cache_id.push_back(mid); mat_cache_ix.push_back(mix); }
-    P.mat = mix;
-    pids[i] = d->prim_id ? d->prim_id[i] : i;
-  }
+  });
+  if (bad_prim.load() >= 0) { const int i = bad_prim.load(); delete s; return fail(RT_ERR_INVALID, "primitive %d has unknown kind %d", i, d->prim_kind[i]); }
+  lap("primitives + normals");
   // leaves: mark the last primitive, give planes their leaf box
   std::vector<char> in_leaf(np, 0);
   for (int i = 0; i < nn; ++i) {
@@ -329,6 +361,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
   }
 
+  lap("leaves + ref node arrays");
   // ---- the render core's own tree over the same primitives (rt_fastbvh.h).  Boxes: triangles as Triangle.hs:24-28
   //      (vertex extent padded by 1e-8), spheres as Sphere.hs:20-22, planes by the box of their reference leaf -
   //      the only region where the reference can see them (Plane.hs:20).
@@ -339,32 +372,37 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   bool fast_ok = !is_leaf(0);
   if (fast_ok) {
     std::vector<double> pbox((size_t)np * 6);
-    for (int i = 0; i < np && fast_ok; ++i) {
-      double *b = &pbox[6 * (size_t)i];
-      const uint32_t kind = prims[i].kind & DPRIM_KIND_MASK;
-      if (kind == RT_PRIM_TRIANGLE) {
-        const double *v = d->prim_data + 9 * (size_t)i;
-        for (int q = 0; q < 3; ++q) {
-          b[q] = std::min(v[q], std::min(v[3 + q], v[6 + q])) - 1e-8;
-          b[3 + q] = std::max(v[q], std::max(v[3 + q], v[6 + q])) + 1e-8;
+    std::atomic<bool> finite(true);
+    parallel_for((size_t)np, n_host_threads, [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; ++i) {
+        double *b = &pbox[6 * i];
+        const uint32_t kind = prims[i].kind & DPRIM_KIND_MASK;
+        if (kind == RT_PRIM_TRIANGLE) {
+          const double *v = d->prim_data + 9 * i;
+          for (int q = 0; q < 3; ++q) {
+            b[q] = std::min(v[q], std::min(v[3 + q], v[6 + q])) - 1e-8;
+            b[3 + q] = std::max(v[q], std::max(v[3 + q], v[6 + q])) + 1e-8;
+          }
+        } else if (kind == RT_PRIM_SPHERE) {
+          const double r = std::fabs(prims[i].d[3]);
+          for (int q = 0; q < 3; ++q) { b[q] = prims[i].d[q] - r; b[3 + q] = prims[i].d[q] + r; }
+        } else {
+          const double *lb = &plane_boxes[6 * (size_t)prims[i].d[6]];
+          for (int q = 0; q < 6; ++q) b[q] = lb[q];
         }
-      } else if (kind == RT_PRIM_SPHERE) {
-        const double r = std::fabs(prims[i].d[3]);
-        for (int q = 0; q < 3; ++q) { b[q] = prims[i].d[q] - r; b[3 + q] = prims[i].d[q] + r; }
-      } else {
-        const double *lb = &plane_boxes[6 * (size_t)prims[i].d[6]];
-        for (int q = 0; q < 6; ++q) b[q] = lb[q];
+        for (int q = 0; q < 6; ++q) if (!std::isfinite(b[q])) finite.store(false);
       }
-      for (int q = 0; q < 6; ++q) if (!std::isfinite(b[q])) fast_ok = false;
-    }
+    });
+    fast_ok = finite.load();
     if (fast_ok) {
-      int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-      if (const char *env = getenv("RT_BUILD_THREADS")) nt = std::max(1, atoi(env));
+      const int nt = n_host_threads;
       int max_leaf = 4;
       double cost_isect = 1.2;
       if (const char *env = getenv("RT_FAST_LEAF")) max_leaf = std::max(1, atoi(env));        // experiment knobs
       if (const char *env = getenv("RT_FAST_CI")) cost_isect = atof(env);
+      lap("primitive boxes");
       build_fast_bvh(np, pbox.data(), max_leaf, cost_isect, nt, fb);
+      lap("fast tree build");
       if (fb.depth > 60) fast_ok = false;
     }
   }
@@ -407,11 +445,14 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
     // primitives in this tree's leaf order; the material slot carries the index in the reference's order instead
     fprims.resize(np);
-    for (int q = 0; q < np; ++q) { fprims[q] = prims[fb.order[q]]; fprims[q].mat = fb.order[q]; fprims[q].kind &= ~DPRIM_LAST; }
+    parallel_for((size_t)np, n_host_threads, [&](size_t q0, size_t q1) {
+      for (size_t q = q0; q < q1; ++q) { fprims[q] = prims[fb.order[q]]; fprims[q].mat = fb.order[q]; fprims[q].kind &= ~DPRIM_LAST; }
+    });
     for (size_t i = 0; i < fb.child.size() / 2; ++i)
       if (f_leaf((int)i)) fprims[(size_t)(-1 - fb.child[2 * i]) + fb.child[2 * i + 1] - 1].kind |= DPRIM_LAST;
   }
   s->has_fast = fast_ok;
+  lap("fast tree order + prims");
 
   std::vector<DLight> lights(std::max(1, d->n_lights));
   std::memset(lights.data(), 0, lights.size() * sizeof(DLight));
@@ -448,6 +489,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   unsigned long long zs[STAT_COUNT] = {0};
   UP(dev_upload(&s->d_stats, zs, STAT_COUNT));
 #undef UP
+  lap("uploads");
   if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
 
   KScene &k = s->ks;
