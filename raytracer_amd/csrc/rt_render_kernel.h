@@ -56,6 +56,14 @@
 #ifndef RT_PRIM_UNROLL
 #define RT_PRIM_UNROLL 1    // primitive tests per PRIM trip
 #endif
+// FAST mode (the core's own tree: 5.2 node visits and 1.2 primitive tests per ray, no speculation), C4 kernel ms for
+// node visits x primitive tests per trip: 5x1 43.5, 4x1 42.9, 5x2 42.8, 4x2 42.2, 3x2 43.5, 4x3 44.2, 6x1 44.1
+#ifndef RT_NODE_UNROLL_FAST
+#define RT_NODE_UNROLL_FAST 4
+#endif
+#ifndef RT_PRIM_UNROLL_FAST
+#define RT_PRIM_UNROLL_FAST 2
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 24    // idle lanes are given new items once this many wait (or none is live): the refill costs the whole wave
 #endif
@@ -188,7 +196,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   // Speculative traversal (FP32 boxes only; the FP64 parity mode visits exactly the reference's nodes): `pend` is a
   // postponed leaf (0 = none).  Leaves are still tested in traversal order (pend before cur), so ties resolve as in
   // the reference; nodes visited before the postponed leaf has narrowed the interval are a superset of the reference's.
-  constexpr bool SPEC = (RT_SPECULATE != 0) && sizeof(BT) == 4;
+  constexpr bool SPEC = (RT_SPECULATE != 0) && sizeof(BT) == 4 && !FAST;   // on the core's own tree rays touch ~1 leaf: postponing it only adds node visits (44.7 -> 43.6 ms without)
+  constexpr int NODE_UNROLL = FAST ? RT_NODE_UNROLL_FAST : RT_NODE_UNROLL, PRIM_UNROLL = FAST ? RT_PRIM_UNROLL_FAST : RT_PRIM_UNROLL;
   int pend = 0;
   // the primitive the path last hit (| HITP_FRONT): kept in a register across the shadow queries, so that SHADE can
   // address its normal and material in the FIRST round of loads instead of after reading them from the record
@@ -490,7 +499,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       RT_TICK(0);
       RT_MARK("NODE_BEGIN");
 #pragma unroll
-      for (int it = 0; it < RT_NODE_UNROLL; ++it) {
+      for (int it = 0; it < NODE_UNROLL; ++it) {
         bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
         if (SPEC) {                                          // postpone a freshly reached leaf and go on with the next stack entry
           const bool spec = (uint32_t)cur > (uint32_t)CUR_POP && pend == 0 && sp > 0;
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       RT_TICK(0);
       RT_MARK("PRIM_BEGIN");
 #pragma unroll
-      for (int it = 0; it < RT_PRIM_UNROLL; ++it) {
+      for (int it = 0; it < PRIM_UNROLL; ++it) {
         const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
         const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_POP;
         const int pi = ~(use_p ? pend : cur);
