@@ -328,6 +328,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
       }
     }
   }
+  for (int i = 0; i < np; ++i)
+    if (!in_leaf[i]) { delete s; return fail(RT_ERR_INVALID, "primitive %d belongs to no leaf of the tree", i); }
   for (int q = 0; q < 6; ++q) maxabs = std::max(maxabs, std::fabs(d->node_bounds[q]));
 
   // ---- internal nodes: children's boxes, FP64 as given and FP32 rounded outward

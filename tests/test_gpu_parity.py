@@ -176,6 +176,12 @@ def test_error_paths(need_gpu):
     a["node_child"][0, 1] = 999          # dangling child index must be rejected on the host, not fault the GPU
     with pytest.raises(F.RtError):
         api.GpuScene(spec, desc_arrays=a)
+    a = api.HostBvh(*spec.all_objects(), spec.leaf_threshold, spec.bvh_max_depth).arrays()
+    leaf = np.nonzero(a["node_child"][:, 0] < 0)[0][0]
+    if a["node_child"][leaf, 1] > 1:
+        a["node_child"][leaf, 1] -= 1    # a primitive no leaf holds: the two trees of the core would disagree about it
+        with pytest.raises(F.RtError):
+            api.GpuScene(spec, desc_arrays=a)
 
 
 def test_arithmetic_is_contraction_free(need_gpu):
