@@ -5,6 +5,8 @@
 //   parseMaterial         app/Parser/Material.hs:11-57
 // including the quirks SURVEY.md §5.6 lists: JSON material ids from 1, MTL ids from 0 in name order,
 // left-biased unions, 3-gons emitted as (v0, v2, v1), n-gons fanned un-flipped, config triangles twice.
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +16,7 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/rthost.h"
@@ -219,6 +222,35 @@ bool read_file(const std::string &path, std::string &out) {
   std::ostringstream ss; ss << f.rdbuf(); out = ss.str();
   return true;
 }
+// allocation-free tokens for the OBJ reader: pointer ranges into the file text (`words`: split at any white space)
+struct Tok { const char *b, *e; };
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; }
+inline void split_words(const char *b, const char *e, std::vector<Tok> &out) {
+  out.clear();
+  while (b < e) {
+    while (b < e && is_ws(*b)) ++b;
+    if (b >= e) break;
+    const char *s = b;
+    while (b < e && !is_ws(*b)) ++b;
+    out.push_back(Tok{s, b});
+  }
+}
+inline bool tok_is(const Tok &t, const char *lit) { const size_t n = strlen(lit); return (size_t)(t.e - t.b) == n && memcmp(t.b, lit, n) == 0; }
+inline bool tok_double(const Tok &t, double &out) {          // same acceptance as read_double below
+  const size_t n = (size_t)(t.e - t.b);
+  char buf[64];
+  if (n == 0) return false;
+  if (n < sizeof buf) { memcpy(buf, t.b, n); buf[n] = 0; char *e = nullptr; out = strtod(buf, &e); return e == buf + n; }
+  const std::string s(t.b, n); char *e = nullptr; out = strtod(s.c_str(), &e); return e != s.c_str() && *e == 0;
+}
+inline bool tok_long(const Tok &t, long &out) {
+  const size_t n = (size_t)(t.e - t.b);
+  char buf[32];
+  if (n == 0 || n >= sizeof buf) return false;
+  memcpy(buf, t.b, n); buf[n] = 0;
+  char *e = nullptr; out = strtol(buf, &e, 10);
+  return e == buf + n;
+}
 bool read_double(const std::string &s, double &out) {
   char *e = nullptr;
   out = strtod(s.c_str(), &e);
@@ -358,7 +390,15 @@ int rth_config_load(const char *json_path, rth_config **out) {
   for (size_t i = 0; i < entries.size(); ++i) {
     if (!read_file(entries[i].path, objTexts[i])) return fail(RT_ERR_INVALID, "%s: openFile: does not exist (No such file or directory)", entries[i].path.c_str());
     std::string mtlLine;
-    for (auto &l : lines_of(objTexts[i])) if (l.rfind("mtllib", 0) == 0) { mtlLine = l; break; }
+    {                                                                          // first line that starts with "mtllib"
+      const std::string &t = objTexts[i];
+      for (size_t b0 = 0; b0 < t.size();) {
+        size_t e0 = t.find('\n', b0);
+        if (e0 == std::string::npos) e0 = t.size();
+        if (e0 - b0 >= 6 && t.compare(b0, 6, "mtllib") == 0) { mtlLine = t.substr(b0, e0 - b0); break; }
+        b0 = e0 + 1;
+      }
+    }
     auto w = words(mtlLine);
     std::string mtlText;
     if (w.size() == 2 && w[0] == "mtllib") {
@@ -423,50 +463,89 @@ int rth_config_load(const char *json_path, rth_config **out) {
   // configTriangles first (SceneParser.hs:70-72)
   int nTri = 0;
   for (auto &h : hittables) if (h.kind == RT_PRIM_TRIANGLE) { push_obj(h.kind, h.d, h.mat); ++nTri; }
-  // ---- Phase 4: OBJ triangles (Parser/Object.hs:16-88)
-  for (size_t i = 0; i < entries.size(); ++i) {
+  // ---- Phase 4: OBJ triangles (Parser/Object.hs:16-88).  Files are independent: each is parsed by its own thread into
+  //      its own arrays (no per-line strings: tokens are pointer ranges into the file text), then appended in file order,
+  //      so the object list and the first error reported are those of the sequential reference.
+  struct ObjOut { std::vector<double> data; std::vector<int32_t> mat; std::string err; bool empty = false; };
+  std::vector<ObjOut> parsed(entries.size());
+  auto parse_obj_file = [&](size_t i) {
+    ObjOut &o = parsed[i];
     const std::string &content = objTexts[i];
-    if (content.empty()) { fprintf(stderr, "Error: OBJ file is empty or could not be read.\n"); continue; }   // Object.hs:79-82
-    auto ls = lines_of(content);
+    if (content.empty()) { o.empty = true; return; }                             // Object.hs:79-82
+    const char *tb = content.data(), *te = tb + content.size();
+    auto next_line = [&](const char *&p, const char *&lb, const char *&le) {   // `lines`: split at \n, the terminator dropped
+      if (p >= te) return false;
+      lb = p;
+      const char *nl = (const char *)memchr(p, '\n', (size_t)(te - p));
+      le = nl ? nl : te;
+      p = nl ? nl + 1 : te;
+      return true;
+    };
+    std::vector<Tok> w;
     std::vector<double> verts;
-    for (auto &l : ls) {
-      if (l.rfind("v ", 0) != 0) continue;                                     // "v " `isPrefixOf` l, :19
-      auto w = words(l);
+    const char *p = tb, *lb, *le;
+    while (next_line(p, lb, le)) {
+      if (le - lb < 2 || lb[0] != 'v' || lb[1] != ' ') continue;                 // "v " `isPrefixOf` l, :19
+      split_words(lb, le, w);
       double x, y, z;
-      if (w.size() != 4 || !read_double(w[1], x) || !read_double(w[2], y) || !read_double(w[3], z))
-        return fail(RT_ERR_INVALID, "Invalid vertex format in .obj file");     // :40
+      if (w.size() != 4 || !tok_double(w[1], x) || !tok_double(w[2], y) || !tok_double(w[3], z)) { o.err = "Invalid vertex format in .obj file"; return; }   // :40
       verts.push_back(x); verts.push_back(y); verts.push_back(z);
     }
     const long nv = (long)verts.size() / 3;
-    bool haveMat = false; std::string curMat;
-    for (auto &l : ls) {
-      auto w = words(l);
-      if (w.size() >= 2 && w[0] == "usemtl") { haveMat = true; curMat = w[1]; continue; }   // :27-28
-      if (w.empty() || w[0] != "f") continue;
-      int matId = 0;                                                           // :30
-      if (haveMat) { auto it = nameToId.find(curMat); if (it != nameToId.end()) matId = it->second; }
-      if (w.size() < 4) return fail(RT_ERR_INVALID, "Invalid face format in .obj file");    // :67
-      std::vector<long> fv;
+    bool haveMat = false; int curMatId = 0;
+    std::vector<long> fv;
+    p = tb;
+    while (next_line(p, lb, le)) {
+      split_words(lb, le, w);
+      if (w.size() >= 2 && tok_is(w[0], "usemtl")) {                             // :27-28
+        haveMat = true;
+        auto it = nameToId.find(std::string(w[1].b, w[1].e));
+        curMatId = it == nameToId.end() ? 0 : it->second;
+        continue;
+      }
+      if (w.empty() || !tok_is(w[0], "f")) continue;
+      const int matId = haveMat ? curMatId : 0;                                  // :30
+      if (w.size() < 4) { o.err = "Invalid face format in .obj file"; return; }  // :67
+      fv.clear();
       for (size_t k = 1; k < w.size(); ++k) {
-        std::string tok = w[k].substr(0, w[k].find('/'));                      // takeWhile (/= '/'), :47
-        char *e = nullptr;
-        long ix = strtol(tok.c_str(), &e, 10);
-        if (e == tok.c_str() || *e) return fail(RT_ERR_INVALID, "Prelude.read: no parse (face index '%s')", tok.c_str());
-        if (ix < 1 || ix > nv) return fail(RT_ERR_INVALID, "Prelude.!!: index out of range (face index %ld, %ld vertices)", ix, nv);
+        const char *sl = (const char *)memchr(w[k].b, '/', (size_t)(w[k].e - w[k].b));   // takeWhile (/= '/'), :47
+        const Tok tok{w[k].b, sl ? sl : w[k].e};
+        long ix;
+        if (!tok_long(tok, ix)) { o.err = "Prelude.read: no parse (face index '" + std::string(tok.b, tok.e) + "')"; return; }
+        if (ix < 1 || ix > nv) { o.err = "Prelude.!!: index out of range (face index " + std::to_string(ix) + ", " + std::to_string(nv) + " vertices)"; return; }
         fv.push_back(ix - 1);
       }
       auto emit = [&](long a, long b, long c) {
         double t[9];
-        for (int k = 0; k < 3; ++k) {                                          // offsetTriangle, :85-86
+        for (int k = 0; k < 3; ++k) {                                            // offsetTriangle, :85-86
           t[k] = verts[3 * a + k] + entries[i].pos[k];
           t[3 + k] = verts[3 * b + k] + entries[i].pos[k];
           t[6 + k] = verts[3 * c + k] + entries[i].pos[k];
         }
-        push_obj(RT_PRIM_TRIANGLE, t, matId); ++nTri;
+        o.data.insert(o.data.end(), t, t + 9); o.mat.push_back(matId);
       };
-      if (fv.size() == 3) emit(fv[0], fv[2], fv[1]);                           // :49-57 (v0, v2, v1)
+      if (fv.size() == 3) emit(fv[0], fv[2], fv[1]);                             // :49-57 (v0, v2, v1)
       else for (size_t k = 1; k + 1 < fv.size(); ++k) emit(fv[0], fv[k], fv[k + 1]);   // :59-66 fan, un-flipped
     }
+  };
+  {
+    const size_t nt = std::min<size_t>(entries.size(), std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+    std::atomic<size_t> next_file(0);
+    std::vector<std::thread> pool;
+    auto work = [&]() { for (size_t i; (i = next_file.fetch_add(1)) < entries.size();) parse_obj_file(i); };
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+  }
+  for (size_t i = 0; i < entries.size(); ++i) {
+    ObjOut &o = parsed[i];
+    if (o.empty) { fprintf(stderr, "Error: OBJ file is empty or could not be read.\n"); continue; }
+    if (!o.err.empty()) return fail(RT_ERR_INVALID, "%s", o.err.c_str());
+    cfg->data.insert(cfg->data.end(), o.data.begin(), o.data.end());
+    cfg->kind.insert(cfg->kind.end(), o.mat.size(), RT_PRIM_TRIANGLE);
+    cfg->material.insert(cfg->material.end(), o.mat.begin(), o.mat.end());
+    nTri += (int)o.mat.size();
+    ObjOut().data.swap(o.data);
   }
   // all config objects again (SceneParser.hs:73)
   for (auto &h : hittables) push_obj(h.kind, h.d, h.mat);
