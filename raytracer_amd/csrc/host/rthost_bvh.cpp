@@ -8,12 +8,15 @@
 // Compile with -ffp-contract=off: the centroid key 0.5*(lo+hi) must round like the reference's.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -90,6 +93,14 @@ int rth_bvh_build(int32_t n, const int32_t *kind, const double *data, const int3
   for (int i = 0; i < n; ++i)
     if (kind[i] < RT_PRIM_TRIANGLE || kind[i] > RT_PRIM_PLANE) return fail(RT_ERR_INVALID, "object %d has unknown kind %d", i, kind[i]);
 
+  const bool dbg_t = getenv("RTH_DEBUG") != nullptr;      // RTH_DEBUG: where the build time goes
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "rthost: bvh_build %-24s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   std::vector<Box> boxes((size_t)n);
   for (int i = 0; i < n; ++i) boxes[i] = prim_box(kind[i], data + 9 * (size_t)i);   // cachedObjs, BVH.hs:31
 
@@ -103,6 +114,7 @@ int rth_bvh_build(int32_t n, const int32_t *kind, const double *data, const int3
 
   std::vector<int32_t> idx((size_t)n);
   for (int i = 0; i < n; ++i) idx[i] = i;
+  lap("boxes + allocation");
 
   std::mutex mu;
   std::condition_variable cv;
@@ -157,8 +169,31 @@ int rth_bvh_build(int32_t n, const int32_t *kind, const double *data, const int3
       const Box &o = boxes[idx[t.b + i]];
       keyed[i] = {0.5 * (o.lo[axis] + o.hi[axis]), idx[t.b + i]};
     }
-    std::stable_sort(keyed.begin(), keyed.end(),
-                     [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first < b.first; });
+    auto by_key = [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first < b.first; };
+    if (parallel && count >= (1L << 18)) {
+      // the top nodes are the serial part of the build: sort pieces on their own threads, then merge neighbours
+      // (stable pieces merged in position order = the stable sort of the whole)
+      int pieces = 1;
+      while (pieces * 2 <= std::min(n_threads, 16)) pieces *= 2;
+      std::vector<long> cut(pieces + 1);
+      for (int k = 0; k <= pieces; ++k) cut[k] = count * k / pieces;
+      {
+        std::vector<std::future<void>> fs;
+        for (int k = 0; k < pieces; ++k)
+          fs.push_back(std::async(std::launch::async, [&, k]() { std::stable_sort(keyed.begin() + cut[k], keyed.begin() + cut[k + 1], by_key); }));
+        for (auto &f : fs) f.get();
+      }
+      for (int w = 1; w < pieces; w *= 2) {
+        std::vector<std::future<void>> fs;
+        for (int k = 0; k + w < pieces; k += 2 * w)
+          fs.push_back(std::async(std::launch::async, [&, k, w]() {
+            std::inplace_merge(keyed.begin() + cut[k], keyed.begin() + cut[k + w], keyed.begin() + cut[std::min(pieces, k + 2 * w)], by_key);
+          }));
+        for (auto &f : fs) f.get();
+      }
+    } else {
+      std::stable_sort(keyed.begin(), keyed.end(), by_key);
+    }
     for (long i = 0; i < count; ++i) idx[t.b + i] = keyed[i].second;
     const long half = count / 2;                                                      // :42
     const long lnodes = subtree_nodes(half, t.depth + 1, leaf_thr, max_depth);
@@ -192,6 +227,7 @@ int rth_bvh_build(int32_t n, const int32_t *kind, const double *data, const int3
     for (int i = 0; i < n_threads; ++i) th.emplace_back(worker);
     for (auto &x : th) x.join();
   }
+  lap("sorts + leaves");
   // internal boxes bottom-up: in pre-order a child's index is larger than its parent's (BVH.hs:45)
   for (long i = total_nodes - 1; i >= 0; --i) {
     if (bvh->node_child[2 * i] < 0) continue;
@@ -200,6 +236,7 @@ int rth_bvh_build(int32_t n, const int32_t *kind, const double *data, const int3
     double *nb = bvh->node_bounds.data() + 6 * i;
     for (int k = 0; k < 3; ++k) { nb[k] = std::min(r[k], l[k]); nb[3 + k] = std::max(r[3 + k], l[3 + k]); }
   }
+  lap("internal boxes");
   bvh->n_leaves = n_leaves.load();
   bvh->depth = max_d.load();
   *out = bvh;
