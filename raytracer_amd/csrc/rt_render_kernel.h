@@ -582,8 +582,13 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         }
         if (STATS && isl && kind == RT_PRIM_TRIANGLE) st[STAT_TRI]++;
         if (__ballot(isl && kind != RT_PRIM_TRIANGLE) != 0ull) {   // wave-uniform: leaves with spheres/planes are rare
-          if (isl && kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro, rd, RT_TMIN, best_t, t); }
-          else if (isl && kind == RT_PRIM_PLANE) { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro, rd, RT_TMIN, best_t, t); }
+          // The ray enters this branch through an opaque copy: otherwise the compiler hoists what depends on the ray alone
+          // (the plane's three FP64 reciprocals 1/d and its parallel-axis tests, the sphere's d.d: ~55 of ~190 VALU
+          // instructions) in front of the branch and every triangle test pays for it.
+          d3 ro_ = ro, rd_ = rd;
+          asm volatile("" : "+v"(ro_.x), "+v"(ro_.y), "+v"(ro_.z), "+v"(rd_.x), "+v"(rd_.y), "+v"(rd_.z));
+          if (isl && kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t); }
+          else if (isl && kind == RT_PRIM_PLANE) { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t); }
         }
         h = h && isl;
         if constexpr (FAST) {                                // this tree's order is not the reference's: settle exact ties its way
