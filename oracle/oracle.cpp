@@ -8,7 +8,9 @@
 // container, the reference has no test-suite, no golden vectors and no
 // fixture scenes (raytracer.cabal defines two executables only; .gitignore:28-33 drops
 // all assets).  Fidelity therefore rests on following the cited source lines literally
-// and on the hand-derived known-answer tests in tests/test_oracle_kat.py.
+// and on the hand-derived known-answer tests in tests/test_oracle_kat.py; a second, separately
+// written restatement (oracle/pyref.py) must agree with this one bit for bit
+// (tests/test_oracle_pyref.py).
 //
 // Every function names the reference lines it restates (paths relative to
 // /root/reference/app).  Arithmetic is binary64 with the reference's operation order;

@@ -1,0 +1,62 @@
+"""Two independent restatements of the reference must agree bit for bit.
+
+The C++ oracle (oracle/oracle.cpp) is what the GPU is compared with, and nothing from the reference pins it (no ghc,
+no tests, no assets: parity unpinned).  oracle/pyref.py is a second reading of the same Haskell sources — recursive and
+list-shaped like the reference, written separately — so a slip in either restatement (a tie rule, an interval bound, the
+order of a sum, ray0 at depth 0 ...) shows up here as a difference.  Frames are tiny: pyref is pure Python."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import pyref
+from raytracer_amd import scenes
+
+
+def both(spec):
+    scene, cam = pyref.scene_from_spec(spec)
+    rad, col, rgb, ids = pyref.render(scene, cam, spec.width, spec.height, spec.spp, spec.antialiasing, spec.max_bounces,
+                                      spec.exposure, spec.gamma, seed=spec.seed)
+    o = O.OracleScene(spec)
+    ref = o.render(n_threads=2)
+    o.close()
+    return (np.array(rad), np.array(col), np.array(rgb, dtype=np.uint8), np.array(ids, dtype=np.int32)), ref
+
+
+def check(spec):
+    (rad, col, rgb, ids), ref = both(spec)
+    assert (ids == ref["prim_id"]).all(), f"{(ids != ref['prim_id']).sum()} primary ids differ"
+    assert np.array_equal(rad, ref["radiance"]), f"radiance differs by up to {np.abs(rad - ref['radiance']).max():.3e}"
+    assert np.abs(col - ref["color"]).max() <= 1e-15          # `**` goes through two pow implementations
+    assert (rgb == ref["rgb8"]).all()
+
+
+def test_c1_deterministic_and_stochastic():
+    check(scenes.c1_testing(width=24, height=14, spp=1))                                       # deterministic: AA off, maxBounces 1
+    check(scenes.c1_testing(width=20, height=12, spp=2, antialiasing=True, max_bounces=4))     # emissive lamp, two lights
+
+
+def test_c2_glass_metal_planes_duplicates():
+    spec = scenes.c2_spheres(width=24, height=14, spp=3)                                       # glass, metal, 3 lights, duplicated ground
+    spec.config_objects.append(("plane", [0.0, 0.0005, 0.0], [0.0, 1.0, 0.0], "blue"))
+    spec.leaf_threshold = 2
+    check(spec)
+
+
+def test_c3_mesh_depth_limited_leaves():
+    check(scenes.c3_blob988(width=20, height=12, spp=2, max_bounces=3, bvh_max_depth=5))       # 31-triangle leaves
+    check(scenes.c3_blob988(width=16, height=10, spp=1, max_bounces=5, leaf_threshold=1))
+
+
+@pytest.mark.parametrize("fmt", ["rgbf", "rgb8"])
+def test_sky_sphere_and_aperture(fmt):
+    spec = scenes.c1_testing(width=18, height=10, spp=2, antialiasing=True, max_bounces=3)
+    spec.sky = scenes.sky_gradient_texture(fmt=fmt)
+    spec.camera["aperture"] = 0.3
+    check(spec)
+
+
+def test_single_leaf_root_and_no_lights():
+    spec = scenes.c2_spheres(width=16, height=10, spp=2)
+    spec.leaf_threshold = 64                                                                   # the whole scene in the root leaf: no box test at all
+    spec.lights = []
+    check(spec)
