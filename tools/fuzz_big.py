@@ -4,7 +4,9 @@ import numpy as np
 from test_gpu_fuzz_trees import random_scene
 from raytracer_amd import api
 bad = 0
-for seed in range(100, 140):
+import sys as _s
+lo_, hi_ = (int(_s.argv[1]), int(_s.argv[2])) if len(_s.argv) > 2 else (100, 140)
+for seed in range(lo_, hi_):
     spec = random_scene(seed, n_tris=[500, 5000, 40000][seed % 3], width=224, height=128, spp=2)
     g = api.GpuScene(spec)
     a, _ = g.render(box_precision=0)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""What rank 0 of an 8-GPU run does per frame besides its kernel (one GPU stands in; the gather itself is not included):
+render rank 0's tiles, k_resolve, un-tile 8 packed buffers, quantise."""
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from raytracer_amd import api, scenes, _ffi as F
+from raytracer_amd import dist as rdist
+spec = scenes.c4_blob63k()
+W, H, world = spec.width, spec.height, 8
+g = api.GpuScene(spec, n_threads=8)
+stream = torch.cuda.current_stream().cuda_stream
+n_max = rdist.max_tiles(W, H, world)
+packed = torch.zeros((n_max * 64, 3), dtype=torch.float64, device="cuda")
+bufs = [torch.zeros_like(packed) for _ in range(world)]
+image = torch.empty((H, W, 3), dtype=torch.float64, device="cuda"); rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
+def step():
+    g.render_tiles_device(0, world, d_color=packed.data_ptr(), stream=stream)
+    bufs[0].copy_(packed)
+    for r in range(world):
+        rdist.untile_into(image, bufs[r], W, H, r, world)
+    F.check(F.core().rt_quantize_device(C.c_void_p(image.data_ptr()), C.c_void_p(rgb8.data_ptr()), 3 * W * H, C.c_void_p(stream)))
+for _ in range(3): step()
+torch.cuda.synchronize(); g.kernel_times()
+t0 = time.perf_counter()
+for _ in range(20): step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20 * 1e3
+ms, n = g.kernel_times()
+print(f"rank 0 of 8: step {dt:.3f} ms, render kernel {ms / n:.3f} ms, everything else {dt - ms / n:.3f} ms")
