@@ -3,7 +3,7 @@
 hot path on the 63,432-triangle scene at 1920x1080, 100 spp (config C4), N = 1/2/4/8 GPUs.
 
 One step = one frame: every rank renders its interleaved 8x8 tiles from its HBM-resident scene copy,
-then the packed framebuffers are gathered on rank 0 over RCCL and un-tiled (raytracer_amd/dist.py).
+then quantises them to the 8-bit frame; the packed 8-bit tiles are gathered on rank 0 over RCCL and un-tiled (raytracer_amd/dist.py).
 A ray = one BVH query (primary/bounce closest-hit + shadow any-hit), counted on the device by the
 stats variant of the kernel in an untimed pass (counts are deterministic for a seed).
 
@@ -69,9 +69,9 @@ def main():
     n_local = len(rdist.tile_list_host(W, H, rank, world))
     n_max = rdist.max_tiles(W, H, world)
     packed = torch.zeros((n_max * 64, 3), dtype=torch.float64, device=dev)
-    image = torch.empty((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    packed8 = torch.zeros((n_max * 64, 3), dtype=torch.uint8, device=dev)      # the rank's tiles as the 8-bit frame: what is gathered
     rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-    bufs = [torch.empty_like(packed) for _ in range(world)] if (rank == 0 and world > 1) else None
+    bufs = [torch.empty_like(packed8) for _ in range(world)] if (rank == 0 and world > 1) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- untimed counting passes: rays / nodes / primitive tests of this rank's share (deterministic per seed).
@@ -104,11 +104,12 @@ def main():
         scene.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream)
         if ev is not None:
             ev[1].record()
-        img = rdist.gather_frame(packed, W, H, rank, world, image=image, gather_buffers=bufs)
-        if rank == 0:
-            from raytracer_amd import _ffi as F
-            F.check(F.core().rt_quantize_device(C.c_void_p(img.data_ptr()), C.c_void_p(rgb8.data_ptr()), 3 * W * H, C.c_void_p(stream)))
+        # showPixel's quantisation (RenderWorker.hs:108-109) is per value, so it is applied to the rank's packed tiles and
+        # the 8-bit frame is what crosses xGMI: 3 bytes per pixel instead of 24
+        F.check(F.core().rt_quantize_device(C.c_void_p(packed.data_ptr()), C.c_void_p(packed8.data_ptr()), packed.numel(), C.c_void_p(stream)))
+        rdist.gather_frame(packed8, W, H, rank, world, image=rgb8, gather_buffers=bufs)
 
+    from raytracer_amd import _ffi as F
     for _ in range(args.warmup):
         step()
     scene.kernel_times()                                             # discard the launches so far

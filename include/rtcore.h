@@ -223,6 +223,11 @@ int  rt_kernel_times(rt_scene *scene, double *sum_ms, int32_t *n_launches);
 int  rt_untile_device(int32_t width, int32_t height, int32_t rank, int32_t world,
                       const void *d_packed, void *d_image, int32_t n_comp, void *stream);
 
+/* The same for slots of n_bytes BYTES each (no alignment assumed): used to gather the 8-bit frame, i.e. packed colours
+ * quantised per rank with rt_quantize_device (3 bytes per pixel over xGMI instead of 24). */
+int  rt_untile_bytes_device(int32_t width, int32_t height, int32_t rank, int32_t world,
+                            const void *d_packed, void *d_image, int32_t n_bytes, void *stream);
+
 /* Device image of 3*W*H doubles (color) -> 3*W*H uint8 (showPixel quantisation), on `stream`. */
 int  rt_quantize_device(const void *d_color, void *d_rgb8, int64_t n_values, void *stream);
 

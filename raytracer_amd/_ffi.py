@@ -95,6 +95,7 @@ RTCORE_SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]),
     "rt_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "rt_untile_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rt_untile_bytes_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_quantize_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rt_fast_bvh_build": (C.c_int, [C.c_int32, c_double_p, C.c_int32, C.c_int32, c_double_p, c_int32_p, c_int32_p, c_int32_p]),
 }

@@ -329,6 +329,18 @@ __global__ void k_untile(const int32_t *tiles, int n_tiles, int tiles_x, int W, 
   for (int c = 0; c < n_comp; ++c) image[dst + c] = packed[slot * n_comp + c];
 }
 
+// the same scatter for slots of n_bytes bytes each (the 8-bit frame: 3 bytes per pixel)
+__global__ void k_untile_bytes(const int32_t *tiles, int n_tiles, int tiles_x, int W, int H, int n_bytes,
+                               const uint8_t *packed, uint8_t *image) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (size_t)n_tiles * 64) return;
+  const int tile = tiles[slot >> 6], lane = (int)(slot & 63);
+  const int px = (tile % tiles_x) * 8 + (lane & 7), py = (tile / tiles_x) * 8 + (lane >> 3);
+  if (px >= W || py >= H) return;
+  const size_t dst = ((size_t)py * W + px) * n_bytes;
+  for (int c = 0; c < n_bytes; ++c) image[dst + c] = packed[slot * n_bytes + c];
+}
+
 __global__ void k_quantize(const double *color, uint8_t *rgb8, long long n) {       // showPixel, RenderWorker.hs:108-109
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

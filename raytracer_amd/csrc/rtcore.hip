@@ -850,6 +850,22 @@ int rt_untile_device(int32_t W, int32_t H, int32_t rank, int32_t world, const vo
   return RT_OK;
 }
 
+int rt_untile_bytes_device(int32_t W, int32_t H, int32_t rank, int32_t world, const void *d_packed, void *d_image,
+                           int32_t n_bytes, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!d_packed || !d_image || n_bytes <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
+  int n = 0;
+  const int32_t *d_t = nullptr;
+  if ((rc = cached_tiles(W, H, rank, world, &d_t, &n))) return rc;
+  if (n == 0) return RT_OK;
+  const size_t slots = (size_t)n * 64;
+  hipLaunchKernelGGL(k_untile_bytes, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_t, n, tiles_x_of(W), W, H, n_bytes, (const uint8_t *)d_packed, (uint8_t *)d_image);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 int rt_quantize_device(const void *d_color, void *d_rgb8, int64_t n_values, void *stream) {
   int rc = ensure_init();
   if (rc) return rc;

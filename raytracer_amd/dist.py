@@ -49,8 +49,12 @@ def untile_into(image: torch.Tensor, packed: torch.Tensor, width, height, rank, 
     n_comp = packed.shape[-1]
     if packed.is_cuda:
         stream = torch.cuda.current_stream().cuda_stream
-        F.check(F.core().rt_untile_device(width, height, rank, world, C.c_void_p(packed.data_ptr()),
-                                          C.c_void_p(image.data_ptr()), n_comp, C.c_void_p(stream)))
+        if packed.dtype == torch.float64:
+            F.check(F.core().rt_untile_device(width, height, rank, world, C.c_void_p(packed.data_ptr()),
+                                              C.c_void_p(image.data_ptr()), n_comp, C.c_void_p(stream)))
+        else:                                  # any other element type goes as bytes (the 8-bit frame: 3 bytes per pixel)
+            F.check(F.core().rt_untile_bytes_device(width, height, rank, world, C.c_void_p(packed.data_ptr()),
+                                                    C.c_void_p(image.data_ptr()), n_comp * packed.element_size(), C.c_void_p(stream)))
         return image
     tiles = tile_list_host(width, height, rank, world)
     if len(tiles) == 0:

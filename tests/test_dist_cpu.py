@@ -46,6 +46,27 @@ def worker(rank, world, port, width, height, out_path):
         dist.destroy_process_group()
 
 
+def worker_u8(rank, world, port, width, height, out_path):
+    """bench.py's exchange: the 8-bit tiles are gathered into preallocated buffers and un-tiled into a preallocated frame."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_max = rdist.max_tiles(width, height, world)
+        packed8 = (fill_packed(width, height, rank, world, n_max).abs() % 251).to(torch.uint8)
+        frame = torch.full((height, width, 3), 9, dtype=torch.uint8) if rank == 0 else None
+        bufs = [torch.empty_like(packed8) for _ in range(world)] if rank == 0 else None
+        for _ in range(2):                                    # the buffers are reused frame after frame
+            img = rdist.gather_frame(packed8, width, height, rank, world, image=frame, gather_buffers=bufs)
+        if rank == 0:
+            assert img is frame
+            np.save(out_path, frame.numpy())
+        else:
+            assert img is None
+    finally:
+        dist.destroy_process_group()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -61,6 +82,15 @@ def test_gather_reassembles_frame(tmp_path, world, width, height):
     img = np.load(out)
     py, px = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
     assert np.array_equal(img, pixel_value(px, py))
+
+
+@pytest.mark.parametrize("world,width,height", [(2, 101, 67), (3, 50, 30)])
+def test_gather_of_the_eight_bit_frame(tmp_path, world, width, height):
+    out = str(tmp_path / "frame8.npy")
+    mp.spawn(worker_u8, args=(world, free_port(), width, height, out), nprocs=world, join=True)
+    py, px = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    want = (torch.from_numpy(pixel_value(px, py)).abs() % 251).to(torch.uint8).numpy()
+    assert np.array_equal(np.load(out), want)
 
 
 def test_world1_untile_and_ownership():

@@ -36,6 +36,29 @@ def test_sharded_render_is_bit_identical(need_gpu, world):
     assert np.array_equal(rad.cpu().numpy(), full["radiance"])
 
 
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_eight_bit_frame_gathered_as_bytes(need_gpu, world):
+    """bench.py's exchange: every rank quantises its packed tiles (rt_quantize_device) and the 8-bit tiles are un-tiled
+    as bytes (rt_untile_bytes_device): the frame must equal rt_render's rgb8 for every world size."""
+    import torch
+    spec = scenes.c3_blob988(width=203, height=117, spp=2)
+    g = api.GpuScene(spec)
+    full, _ = g.render(want=("rgb8",))
+    W, H = spec.width, spec.height
+    n_max = rdist.max_tiles(W, H, world)
+    rgb8 = torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(world):
+        packed = torch.zeros((n_max * 64, 3), dtype=torch.float64, device="cuda")
+        packed8 = torch.zeros((n_max * 64, 3), dtype=torch.uint8, device="cuda")
+        g.render_tiles_device(rank, world, d_color=packed.data_ptr(), stream=stream)
+        F.check(F.core().rt_quantize_device(C.c_void_p(packed.data_ptr()), C.c_void_p(packed8.data_ptr()), packed.numel(), C.c_void_p(stream)))
+        rdist.untile_into(rgb8, packed8, W, H, rank, world)
+    torch.cuda.synchronize()
+    g.close()
+    assert np.array_equal(rgb8.cpu().numpy(), full["rgb8"])
+
+
 def test_quantize_device_matches_host_rule(need_gpu):
     import torch
     c = torch.tensor([0.0, 0.5, 0.999999, 1.0, 0.0039, 1.7, -0.2, float("nan")], dtype=torch.float64, device="cuda")
