@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 /* ---- status codes (error convention replaces `error`/exitFailure, app/Main.hs:24-26) */
 #define RT_OK                 0
@@ -168,6 +168,8 @@ typedef struct rt_stats {
   uint64_t cyc_vote, cyc_node, cyc_prim, cyc_shade, cyc_refill;   /* shader-clock ticks summed over waves, per body */
   uint64_t rays_shadow_culled; /* box_precision = 0 only: shadow queries of the reference NOT traced (and not in rays_shadow)
                                   because the surface faces away from the light: their term is max(0, n.l) = 0 either way */
+  uint64_t rays_literal;       /* queries answered by the literal walk of the reference's tree: a plane was crossed beyond its leaf
+                                  box's exit, where the reference's answer depends on its traversal history (BVH.hs:137-138) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -30,6 +30,7 @@ struct KScene {
   const double *tri_normals;   // 6 doubles per primitive (triangles only): n = normalize(e1 x e2) (Triangle.hs:51) and normalize(n) (Light.hs:19)
   const void *sky;
   int32_t root_ref;
+  int32_t ref_root_ref;        // root of the reference's tree (== root_ref unless FAST)
   int32_t n_lights;
   int32_t bg_kind, sky_format, sky_w, sky_h;
   double bg1[3], bg2[3];
@@ -57,10 +58,11 @@ struct KFrame {
   uint32_t n_items;            // (tile_end - tile_begin) * 64 * spp
   uint32_t chunk;              // items a wave takes from the counter at a time (a multiple of 64, set per launch)
   double *samples;             // [n_items][3] radiance of every path of this launch, summed per pixel by k_resolve
+  int32_t lit_row;             // first row of literal_hit's per-lane stack within a wave's fscratch block (scenes with planes), else -1
   unsigned long long *dbg;     // experiment builds (-DRT_TIMERS) only: 4 words per wave, see the end of k_render_tiles
 };
 
-enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_SHADOW_CULLED, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
+enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_SHADOW_CULLED, STAT_LITERAL, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
 
 // cold code (once per path, not per traversal step).  Inlined: taking KScene/KFrame by reference out of line cost more
 // scratch than it saved registers; only the libm-heavy leaves (sky_uv, pow_gamma) are real calls.
@@ -228,32 +230,114 @@ RT_DEV bool hit_sphere(const DPrim &P, d3 ro, d3 rd, double tmin, double tmax, d
   tout = t1;
   return true;
 }
-// Planes are bounded only by the clipped interval of the leaf that holds them (Plane.hs:20 gives every
-// plane the same slab box), so the leaf's FP64 box is re-tested exactly here.
-RT_DEV bool hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double &tout) {
+// The reference's slab test returning the whole clipped interval (hitAABBInterval, BoundingBox.hs:18-37)
+RT_DEV bool box_interval(const BoxRay<double> &r, const double *bx, double tmin, double tmax, double &tenter, double &texit) {
+  double a0, a1, b0, b1, c0, c1;
+  const double inf = __builtin_huge_val();
+  bool ok = true;
+  if (r.px) { ok = ok && !(r.ox < bx[0] || r.ox > bx[3]); a0 = -inf; a1 = inf; }
+  else { double t0 = (bx[0] - r.ox) * r.ix, t1 = (bx[3] - r.ox) * r.ix; a0 = fmin(t0, t1); a1 = fmax(t0, t1); }
+  if (r.py) { ok = ok && !(r.oy < bx[1] || r.oy > bx[4]); b0 = -inf; b1 = inf; }
+  else { double t0 = (bx[1] - r.oy) * r.iy, t1 = (bx[4] - r.oy) * r.iy; b0 = fmin(t0, t1); b1 = fmax(t0, t1); }
+  if (r.pz) { ok = ok && !(r.oz < bx[2] || r.oz > bx[5]); c0 = -inf; c1 = inf; }
+  else { double t0 = (bx[2] - r.oz) * r.iz, t1 = (bx[5] - r.oz) * r.iz; c0 = fmin(t0, t1); c1 = fmax(t0, t1); }
+  tenter = fmax(fmax(a0, b0), fmax(c0, tmin));                     // :30
+  texit = fmin(fmin(a1, b1), fmin(c1, tmax));                      // :31
+  return ok && tenter <= texit;                                    // :32
+}
+
+// Planes are bounded only by the interval their leaf receives (Plane.hs:20 gives every plane the same slab box,
+// Plane.hs:26 tests `contains interval t`), so the leaf's FP64 box is re-tested exactly here.  That interval
+// is [enter, min(exit, closest so far)] of the leaf's box - except when the leaf is the child visited SECOND and its
+// sibling produced a hit: then it is [enter, t firstHit] (BVH.hs:137-138), which can reach past the box's exit.
+// Returns 0: miss; 1: hit inside the leaf box's own interval - an ordinary candidate whatever the traversal order;
+// 2: the plane is crossed beyond the box's exit but not beyond the closest hit so far: whether the reference sees it
+// depends on its traversal history, and the caller settles the whole query with literal_hit below.
+#define PLANE_MISS 0
+#define PLANE_HIT 1
+#define PLANE_LITERAL 2
+RT_DEV int hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double &tout) {
   d3 pp = mk3(P.d[0], P.d[1], P.d[2]), n = mk3(P.d[3], P.d[4], P.d[5]);
   double denom = dot3(rd, n);                                  // Plane.hs:22
-  if (!(fabs(denom) > 1e-6)) return false;                     // :23
+  if (!(fabs(denom) > 1e-6)) return PLANE_MISS;                // :23
   double t = dot3(pp - ro, n) / denom;                         // :25
-  double lo = tmin, hi = tmax;
-  long long bi = (long long)P.d[6];
-  if (bi >= 0) {
-    BoxRay<double> br;
-    make_boxray(br, ro, rd, 0.0f);
-    double te;
-    const double *bx = plane_boxes + 6 * bi;
-    if (!box_test(br, bx, tmin, tmax, te)) return false;
-    lo = te;
-    // exit distance of the same box (recomputed; box_test only returns the entry)
-    const double inf = __builtin_huge_val();
-    double a1 = br.px ? inf : fmax((bx[0] - br.ox) * br.ix, (bx[3] - br.ox) * br.ix);
-    double b1 = br.py ? inf : fmax((bx[1] - br.oy) * br.iy, (bx[4] - br.oy) * br.iy);
-    double c1 = br.pz ? inf : fmax((bx[2] - br.oz) * br.iz, (bx[5] - br.oz) * br.iz);
-    hi = fmin(fmin(a1, b1), fmin(c1, tmax));
-  }
-  if (!(t >= lo && t <= hi)) return false;                     // :26
   tout = t;
-  return true;
+  long long bi = (long long)P.d[6];
+  if (bi < 0) return (t >= tmin && t <= tmax) ? PLANE_HIT : PLANE_MISS;   // single-leaf root: the raw ray interval (BVH.hs:121, Trace.hs:24)
+  BoxRay<double> br;
+  make_boxray(br, ro, rd, 0.0f);
+  double te, tx;
+  if (!box_interval(br, plane_boxes + 6 * bi, tmin, tmax, te, tx)) return PLANE_MISS;   // the leaf is not entered (or only behind a closer hit)
+  if (!(t >= te && t <= tmax)) return PLANE_MISS;              // :26 (tmax = the closest hit so far)
+  (void)box_interval(br, plane_boxes + 6 * bi, tmin, __builtin_huge_val(), te, tx);     // the box's own exit
+  return t <= tx ? PLANE_HIT : PLANE_LITERAL;
+}
+
+// The reference's `hit` on its own tree (BVH.hs:120-143) walked LITERALLY for one ray: FP64 boxes, every child entered
+// with its clipped interval, the second child with [minVal iSecond, t firstHit] when the first one produced a hit
+// (:137-138), every primitive tested against the interval its leaf received (Triangle.hs:53, Sphere.hs:26, Plane.hs:26).
+// Out of line, per lane, slow, and rare: it runs only for the queries hit_plane reports as PLANE_LITERAL - a plane placed
+// outside its constant slab box (Plane.hs:20), where the reference's answer is a property of ITS traversal.
+// `stk`: this lane's column of 3 * (tree depth) rows of 64 doubles in global memory (ref, lo, hi of the pending second children).
+struct LitHit { double t; int best; };
+__device__ __attribute__((noinline)) LitHit literal_hit(const DNode<double> *nodes, const DPrim *prims, int root_ref, double *stk,
+                                                        double ox, double oy, double oz, double dx, double dy, double dz,
+                                                        double tmin, double tmax) {
+  const d3 ro = mk3(ox, oy, oz), rd = mk3(dx, dy, dz);
+  BoxRay<double> br;
+  make_boxray(br, ro, rd, 0.0f);
+  LitHit r;
+  r.t = tmax; r.best = -1;
+  unsigned long long dirty = 0ull;                   // bit k: some leaf returned a hit since stack entry k was pushed
+  int sp = 0, cur = root_ref;
+  double lo = tmin, hi = tmax;                       // the root is entered with the raw interval, its own box is never tested
+  for (int guard = 0; guard < (1 << 24); ++guard) {
+    bool descend = false;
+    if (cur >= 0) {                                  // BVHInternal
+      const double *bx = nodes[cur].box;
+      const int refL = nodes[cur].ref[0], refR = nodes[cur].ref[1];
+      double eL, xL, eR, xR;
+      const bool hL = box_interval(br, bx, lo, hi, eL, xL);        // :124
+      const bool hR = box_interval(br, bx + 6, lo, hi, eR, xR);
+      if (hL && hR) {
+        const bool lf = eL < eR;                     // :132 (tie => right first)
+        stk[(3 * sp) * 64] = (double)(lf ? refR : refL);
+        stk[(3 * sp + 1) * 64] = lf ? eR : eL;
+        stk[(3 * sp + 2) * 64] = lf ? xR : xL;
+        dirty &= ~(1ull << sp);
+        ++sp;
+        cur = lf ? refL : refR; lo = lf ? eL : eR; hi = lf ? xL : xR;
+        descend = true;
+      } else if (hL) { cur = refL; lo = eL; hi = xL; descend = true; }   // :126
+      else if (hR) { cur = refR; lo = eR; hi = xR; descend = true; }     // :127
+    } else {                                         // BVHLeaf (:121-122), closestHitList (HitHelpers.hs:11-16)
+      bool have = false;
+      double bt = 0.0;
+      int bp = -1;
+      for (int pi = ~cur;; ++pi) {
+        const DPrim P = prims[pi];
+        const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+        double t = 0.0;
+        bool h;
+        if (kind == RT_PRIM_TRIANGLE) h = hit_triangle(P, ro, rd, lo, hi, t);
+        else if (kind == RT_PRIM_SPHERE) h = hit_sphere(P, ro, rd, lo, hi, t);
+        else {
+          const double denom = dot3(rd, mk3(P.d[3], P.d[4], P.d[5]));                    // Plane.hs:22
+          t = dot3(mk3(P.d[0], P.d[1], P.d[2]) - ro, mk3(P.d[3], P.d[4], P.d[5])) / denom;   // :25
+          h = fabs(denom) > 1e-6 && t >= lo && t <= hi;                                  // :23, :26
+        }
+        if (h && (!have || t <= bt)) { have = true; bt = t; bp = pi; }   // foldr closer: a later element wins an equal t
+        if (P.kind & DPRIM_LAST) break;
+      }
+      if (have) { r.t = bt; r.best = bp; dirty = ~0ull; }   // a second child's hit has t <= t firstHit and replaces it (:141)
+    }
+    if (descend) continue;
+    if (sp == 0) break;                              // back at the root: done
+    --sp;
+    cur = (int)stk[(3 * sp) * 64]; lo = stk[(3 * sp + 1) * 64]; hi = stk[(3 * sp + 2) * 64];
+    if ((dirty >> sp) & 1ull) hi = r.t;              // :137-138: newMaxT = t firstHit replaces maxVal iSecond
+  }
+  return r;
 }
 
 RT_DEV unsigned long long wave_sum(unsigned long long v) {

@@ -567,7 +567,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         const uint32_t kind = P.kind & DPRIM_KIND_MASK;
         // Moller-Trumbore without early exits (Triangle.hs:30-53): same operations, same order, the rejections become one predicate
         double t;
-        bool h;
+        bool h, lit_done = false;
         {
           const d3 p0 = mk3(P.d[0], P.d[1], P.d[2]), e1 = mk3(P.d[3], P.d[4], P.d[5]), e2 = mk3(P.d[6], P.d[7], P.d[8]);
           const d3 hh = cross3(rd, e2);                      // :34
@@ -588,7 +588,22 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           d3 ro_ = ro, rd_ = rd;
           asm volatile("" : "+v"(ro_.x), "+v"(ro_.y), "+v"(ro_.z), "+v"(rd_.x), "+v"(rd_.y), "+v"(rd_.z));
           if (isl && kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t); }
-          else if (isl && kind == RT_PRIM_PLANE) { if (STATS) st[STAT_PLANE]++; h = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t); }
+          else if (isl && kind == RT_PRIM_PLANE) {
+            if (STATS) st[STAT_PLANE]++;
+            const int ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);
+            h = ps == PLANE_HIT;
+            if (ps == PLANE_LITERAL) {
+              // The plane is crossed beyond its leaf box's exit: the reference sees it only if that leaf is visited second
+              // and its sibling produced a hit (BVH.hs:137-138) - a property of the reference's traversal, so the whole
+              // query is answered by the literal walk of the reference's tree and this lane's traversal ends here.
+              RT_COLD_ARGS();
+              if (STATS) st[STAT_LITERAL]++;
+              const LitHit lh = literal_hit((const DNode<double> *)sc.ref_nodes64, sc.prims, sc.ref_root_ref, rec + (size_t)fr.lit_row * 64,
+                                            ro_.x, ro_.y, ro_.z, rd_.x, rd_.y, rd_.z, RT_TMIN, li >= 0 ? best_t : RT_TMAX);
+              best = lh.best; best_t = lh.t; tmaxb = tmax_for_boxes<BT>(lh.t);
+              lit_done = true;
+            }
+          }
         }
         h = h && isl;
         if constexpr (FAST) {                                // this tree's order is not the reference's: settle exact ties its way
@@ -607,6 +622,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         cur = isl ? (blocked ? CUR_DONE : ((last || use_p) ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)
         bool pp = isl && !use_p && !blocked && last;
         RT_POP2(pp);
+        cur = lit_done ? CUR_DONE : cur;                     // (rare) the query was answered by literal_hit
+        sp = lit_done ? 0 : sp;
+        if (SPEC) pend = lit_done ? 0 : pend;
       }
       RT_TICK(2);
     }

@@ -104,6 +104,7 @@ struct rt_scene {
   void *d_sky = nullptr;
   KScene ks{};
   int n_internal = 0, depth = 0;
+  bool has_boxed_planes = false;        // some plane sits in a non-root leaf: its visibility can depend on the reference's traversal (literal_hit)
   // per-launch scratch
   uint32_t *d_counter = nullptr;
   unsigned long long *d_stats = nullptr;
@@ -500,6 +501,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
   k.plane_boxes = s->d_plane_boxes; k.tri_normals = s->d_tri_normals; k.sky = s->d_sky;
   k.root_ref = is_leaf(0) ? d->node_child[0] : 0;
+  k.ref_root_ref = k.root_ref;
+  s->has_boxed_planes = !plane_boxes.empty();
   k.n_lights = d->n_lights;
   k.bg_kind = d->bg_kind; k.sky_format = d->sky_format; k.sky_w = d->sky_width; k.sky_h = d->sky_height;
   for (int q = 0; q < 3; ++q) { k.bg1[q] = d->bg_color1[q]; k.bg2[q] = d->bg_color2[q]; }
@@ -579,6 +582,11 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   // per wave: RT_STACK_LDS stack rows + the record's hot rows; deeper stack entries overflow to global memory
   const size_t stack_bytes = (size_t)(RT_STACK_LDS + LR_ROWS) * 64 * sizeof(uint2);
   fr.scratch_rows = PR_ROWS + std::max(0, fr.stack_depth - RT_STACK_LDS);
+  fr.lit_row = -1;
+  if (s->has_boxed_planes) {                                  // literal_hit's per-lane stack: 3 rows per level of the reference's tree
+    fr.lit_row = fr.scratch_rows;
+    fr.scratch_rows += 3 * (std::max(1, s->depth) + 1);
+  }
   int wpb = RT_BLOCK_THREADS / 64;
   if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env)));   // experiment knob
   const size_t lds_cu = 160 * 1024 / RT_BLOCKS_PER_CU;       // LDS one workgroup may use
@@ -728,6 +736,7 @@ static int read_stats(rt_scene *s, rt_stats *st) {
   st->sched_live_lanes = h[STAT_LIVE];
   st->top_node_hits = h[STAT_TOPHIT];
   st->rays_shadow_culled = h[STAT_SHADOW_CULLED];
+  st->rays_literal = h[STAT_LITERAL];
   st->cyc_vote = h[STAT_T_VOTE]; st->cyc_node = h[STAT_T_NODE]; st->cyc_prim = h[STAT_T_PRIM]; st->cyc_shade = h[STAT_T_SHADE]; st->cyc_refill = h[STAT_T_REFILL];
   return RT_OK;
 }

@@ -22,7 +22,7 @@ def test_rtcore_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(F.LIB_DIR, "librtcore.so"))
     for n in names:
         getattr(lib, n)
-    assert F.core().rt_abi_version() == 2
+    assert F.core().rt_abi_version() == 3
 
 
 def test_rthost_exports_every_declared_symbol():

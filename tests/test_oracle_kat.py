@@ -242,3 +242,19 @@ def test_quantisation_truncates():
     # toneMap(1): c/(c+1) -> .5, 1/3, 0 ; gamma 1 ; truncate(c*255.999) (RenderWorker.hs:108-109)
     assert res["rgb8"][0, 0].tolist() == [127, 85, 0]
     assert np.allclose(res["color"][0, 0], [0.5, 1 / 3, 0.0])
+
+
+def test_plane_seen_through_the_second_childs_interval():
+    """sphere c=(0,-9,-6) r=10 (first child, hit at 6.0517) + plane p=(0,-0.5,0), leafThreshold 1.  The plane's
+    leaf box (the constant slab, Plane.hs:20) is left at 4.4744, but as the SECOND child it receives [enter, t firstHit]
+    (BVH.hs:137-138), so the reference returns the plane at t = 5.5902 (= 2.5 / (0.5/sqrt(1.25)))."""
+    from plane_cases import two_object_scene
+    o = O.OracleScene(two_object_scene())
+    d = np.array([0.0, -0.5, -1.0]); d /= np.linalg.norm(d)
+    pid, out = o.hit([0.0, 2.0, 5.0], d)
+    assert pid == 1 and abs(out[0] - 2.5 * np.sqrt(1.25) / 0.5) < 1e-12
+    # a ray that misses the sphere: nothing narrows the interval past the slab's exit, the plane stays invisible
+    d2 = np.array([0.9, -0.5, 0.3]); d2 /= np.linalg.norm(d2)
+    pid2, _ = o.hit([0.0, 2.0, 5.0], d2)
+    assert pid2 == -1
+    o.close()

@@ -60,3 +60,12 @@ def test_single_leaf_root_and_no_lights():
     spec.leaf_threshold = 64                                                                   # the whole scene in the root leaf: no box test at all
     spec.lights = []
     check(spec)
+
+
+def test_planes_outside_their_slab_box():
+    # a leaf visited second after its sibling produced a hit receives [enter, t firstHit] (BVH.hs:137-138): both restatements
+    # must see the plane there, beyond its leaf box's exit
+    from plane_cases import random_plane_scene, two_object_scene
+    check(two_object_scene(width=32, height=18, spp=1))
+    check(two_object_scene(width=20, height=12, spp=2, max_bounces=3, antialiasing=True))
+    check(random_plane_scene(5, n_tris=60, width=20, height=12, spp=1))
