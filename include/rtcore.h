@@ -176,6 +176,14 @@ typedef struct rt_scene rt_scene;
 
 /* Select the device this process renders on (one process per GPU).  device < 0 => current. */
 int  rt_init(int device);
+/* Select a GROUP of devices for a single-process host (the reference is one process that calls createPPM once,
+ * app/Main.hs:53): scenes created afterwards are replicated on every device of the group and ONE blocking rt_render call
+ * fans the frame out over them - tile (tx,ty) to device (tx+ty) mod n, one host thread and one stream per device, the
+ * packed tiles brought to devices[0] as peer copies over xGMI - replacing the 24 green threads and the row TQueue of
+ * app/Rendering/ImageGenerator.hs:37,64-94.  n_devices = 0 with devices = NULL selects every visible device.  Entries may
+ * repeat ("virtual devices": how the tests exercise the fan-out on one GPU).  The frame is bit-identical for every n. */
+int  rt_init_devices(int32_t n_devices, const int32_t *devices);
+int  rt_device_count(void);   /* size of the current group (1 after rt_init) */
 void rt_shutdown(void);
 const char *rt_last_error(void);
 int  rt_abi_version(void);
@@ -193,7 +201,9 @@ void rt_scene_destroy(rt_scene *scene);
 int  rt_fast_bvh_build(int32_t n_prims, const double *boxes, int32_t max_leaf, int32_t n_threads,
                        double *node_bounds, int32_t *node_child, int32_t *order, int32_t *depth);
 
-/* One frame, host buffers in and out: the replacement of the worker fan-out. Blocking. */
+/* One frame, host buffers in and out: the replacement of the worker fan-out. Blocking.  Renders on the device group the
+ * scene was created for (one device after rt_init, n after rt_init_devices); stats->ms_render is the slowest device's
+ * kernel time, the counters are summed over the devices. */
 int  rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                rt_output *out, rt_stats *stats);
 
@@ -217,7 +227,8 @@ int  rt_render_tiles_device(rt_scene *scene, const rt_camera *cam, const rt_para
 
 /* Measurement hook (no counterpart in the reference): sum of the durations, in ms, of the k_render_tiles launches
  * recorded on this scene since the previous call, taken with HIP events on the stream each launch went to, and
- * their number (at most 256 are kept).  Blocks until those launches have finished.  bench.py's roofline uses it. */
+ * their number (at most 256 are kept).  Blocks until those launches have finished.  bench.py's roofline uses it.
+ * For a scene on a device group: the largest per-device sum, and device 0's number of launches. */
 int  rt_kernel_times(rt_scene *scene, double *sum_ms, int32_t *n_launches);
 
 /* Scatters one rank's packed device buffer (n_comp doubles per slot) into a full

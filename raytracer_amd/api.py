@@ -155,10 +155,17 @@ def fill_desc_common(desc: F.rt_scene_desc, spec: SceneSpec, keep: list):
 class GpuScene:
     """A scene resident in HBM (rt_scene).  `desc_arrays` lets tests feed an externally built tree."""
 
-    def __init__(self, spec: SceneSpec, bvh: HostBvh | None = None, desc_arrays: dict | None = None, n_threads=1, device=-1):
+    def __init__(self, spec: SceneSpec, bvh: HostBvh | None = None, desc_arrays: dict | None = None, n_threads=1, device=-1,
+                 devices=None):
+        """device: the one GPU this process renders on (rt_init).  devices: a list of device ids instead - a device group
+        for the single-process fan-out of rt_render (rt_init_devices; ids may repeat: virtual devices for tests)."""
         self.spec = spec
         lib = F.core()
-        F.check(lib.rt_init(device))
+        if devices is not None:
+            arr = np.ascontiguousarray(devices, np.int32)
+            F.check(lib.rt_init_devices(len(arr), _ip(arr)))
+        else:
+            F.check(lib.rt_init(device))
         desc = F.rt_scene_desc()
         keep = []
         if desc_arrays is not None:
@@ -203,14 +210,17 @@ class GpuScene:
         F.check(F.core().rt_kernel_times(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def render_tiles_device(self, rank, world, d_color=0, d_radiance=0, d_prim_id=0, stream=0, camera=None, **param_over):
-        """rt_render_tiles_device: this rank's tiles into device buffers (raw pointers), asynchronous."""
+    def render_tiles_device(self, rank, world, d_color=0, d_radiance=0, d_prim_id=0, stream=0, camera=None, noalloc=False,
+                            **param_over):
+        """rt_render_tiles_device: this rank's tiles into device buffers (raw pointers), asynchronous.
+        noalloc=True: rt_render_tiles_device_noalloc, the variant whose workspace is the library's static device array."""
         p = make_params(self.spec, **param_over)
         st = F.rt_stats()
         cam = camera if camera is not None else self.camera
-        F.check(F.core().rt_render_tiles_device(self._h, C.byref(cam), C.byref(p), rank, world,
-                                                C.c_void_p(d_color or None), C.c_void_p(d_radiance or None),
-                                                C.c_void_p(d_prim_id or None), C.c_void_p(stream or None), C.byref(st)))
+        fn = F.core().rt_render_tiles_device_noalloc if noalloc else F.core().rt_render_tiles_device
+        F.check(fn(self._h, C.byref(cam), C.byref(p), rank, world,
+                   C.c_void_p(d_color or None), C.c_void_p(d_radiance or None),
+                   C.c_void_p(d_prim_id or None), C.c_void_p(stream or None), C.byref(st)))
         return st
 
     def close(self):

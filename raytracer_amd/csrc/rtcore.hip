@@ -42,15 +42,31 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
   } while (0)
 
-struct Ctx {
+// One entry per HIP device this process has initialised (rt_init / rt_init_devices).
+constexpr int RT_MAX_DEVICES = 64;
+struct DevCtx {
   bool ready = false;
-  int device = -1;
   int n_cu = 0;
-  size_t lds_per_block = 0;
-} g_ctx;
+};
+DevCtx g_dev[RT_MAX_DEVICES];
+std::mutex g_init_mu;
+// The devices one rt_render call fans out over (rt_init_devices); entries may repeat ("virtual devices": tests on one GPU).
+std::vector<int> g_group;
+
+int init_device(int device) {            // with `device` current; idempotent
+  std::lock_guard<std::mutex> g(g_init_mu);
+  DevCtx &c = g_dev[device];
+  if (c.ready) return RT_OK;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  c.n_cu = prop.multiProcessorCount;
+  c.ready = true;
+  return RT_OK;
+}
 
 int ensure_init() {
-  if (g_ctx.ready) return RT_OK;
+  int device = 0;
+  if (hipGetDevice(&device) == hipSuccess && device >= 0 && device < RT_MAX_DEVICES && g_dev[device].ready) return RT_OK;
   return rt_init(-1);
 }
 
@@ -84,11 +100,43 @@ template <typename T> int dev_upload(T **dst, const T *src, size_t n) {
 static inline int tiles_x_of(int W) { return (W + 7) / 8; }
 static inline int tiles_y_of(int H) { return (H + 7) / 8; }
 
-struct rt_scene {
+// What a launch needs beyond the scene, its inputs and its outputs.  Either owned by a Replica (hipMalloc'ed, grows on
+// demand, never inside a steady-state loop) or carved out of the static scratch array (fixed: rt_render_tiles_device_noalloc).
+struct Workspace {
+  uint32_t *counter = nullptr;          // chunk counter of the persistent kernel
+  unsigned long long *stats = nullptr;  // STAT_COUNT counters
+  int32_t *tiles = nullptr;             // this rank's tile list (k_make_tiles)
+  size_t tiles_cap = 0;                 // entries
+  double *fscratch = nullptr;           // per resident wave: the lanes' path records (rt_render_kernel.h)
+  size_t fscratch_cap = 0;              // bytes
+  double *samples = nullptr;            // radiance of every path of one launch, [item][3]
+  size_t samples_cap = 0;               // bytes
+  bool fixed = false;                   // true: capacities never change and nothing is ever allocated
+  int tl_w = -1, tl_h = -1, tl_rank = -1, tl_world = -1, tl_n = 0;   // what `tiles` currently holds
+};
+
+// The scene in the kernels' layout, on the host: built once per rt_scene_create, uploaded to every device of the group.
+struct HostScene {
+  std::vector<DNode<float>> n32, fn32;
+  std::vector<DNode<double>> n64;
+  std::vector<DPrim> prims, fprims;
+  std::vector<int32_t> pids, ref_anc, ref_depth, leaf_anc;
+  std::vector<DMaterial> mats;
+  std::vector<DLight> lights;
+  std::vector<double> plane_boxes, tri_normals;
+  const void *sky = nullptr;
+  size_t sky_bytes = 0;
+  bool has_fast = false;
+  int n_internal = 0, depth = 0, f_internal = 0, f_depth = 0, f_root_ref = 0;
+  KScene ks{};                          // the non-pointer fields
+};
+
+// One device's copy of the scene + its launch workspace + cached outputs.
+struct Replica {
   int device = 0;
   // HBM-resident scene
   DNode<float> *d_nodes32 = nullptr;
-  DNode<double> *d_nodes64 = nullptr;   // the reference tree's FP64 boxes: box_precision = 1 and the tie rule of the fast tree
+  DNode<double> *d_nodes64 = nullptr;   // the reference tree's FP64 boxes: box_precision = 1, the tie rule of the fast tree, literal_hit
   DPrim *d_prims = nullptr;
   // the render core's own tree (rt_fastbvh.h); absent when the reference root is a leaf
   bool has_fast = false;
@@ -105,22 +153,21 @@ struct rt_scene {
   KScene ks{};
   int n_internal = 0, depth = 0;
   bool has_boxed_planes = false;        // some plane sits in a non-root leaf: its visibility can depend on the reference's traversal (literal_hit)
-  // per-launch scratch
-  uint32_t *d_counter = nullptr;
-  unsigned long long *d_stats = nullptr;
-  double *d_fscratch = nullptr;         // per resident wave: the lanes' path records (rt_render_kernel.h)
-  size_t fscratch_waves = 0;
-  int fscratch_rows = 0;
-  double *d_samples = nullptr;          // radiance of every path of one launch, [item][3]
-  size_t samples_cap = 0;               // bytes
-  // cached outputs of rt_render
+  Workspace ws;                         // owned, growable
+  // cached outputs of rt_render: full frame (single device, or device 0 of a group) ...
   size_t cap_px = 0;
   double *d_color = nullptr, *d_radiance = nullptr;
   int32_t *d_primid = nullptr;
   uint8_t *d_rgb8 = nullptr;
-  // cached tile list
-  int tl_w = -1, tl_h = -1, tl_rank = -1, tl_world = -1, tl_n = 0;
-  int32_t *d_tiles = nullptr;
+  // ... and, in a device group, this replica's packed tiles (on its device) and where they land on device 0
+  size_t cap_slots = 0;
+  double *p_color = nullptr, *p_radiance = nullptr;
+  int32_t *p_primid = nullptr;
+  uint8_t *p_rgb8 = nullptr;
+  double *g_color = nullptr, *g_radiance = nullptr;     // on the group's device 0 (for replica 0 they alias the p_ buffers)
+  int32_t *g_primid = nullptr;
+  uint8_t *g_rgb8 = nullptr;
+  hipStream_t stream = nullptr;         // this replica's stream in a device group
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // HIP event pairs around the k_render_tiles launches since the last rt_kernel_times call (measurement hook)
   static constexpr int KT_RING = 256;
@@ -128,47 +175,33 @@ struct rt_scene {
   int kt_pending = 0;
 };
 
-extern "C" {
+struct rt_scene {
+  std::vector<Replica *> rep;           // one per device of the group the scene was created for (rep[0]: where frames are assembled)
+};
 
-int rt_abi_version(void) { return RT_ABI_VERSION; }
-const char *rt_last_error(void) { return g_err.c_str(); }
-
-int rt_init(int device) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
-    return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render core has no CPU fallback");
-  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
-  if (device >= n) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", device, n);
-  HIP_TRY(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, device));
-  g_ctx.device = device;
-  g_ctx.n_cu = prop.multiProcessorCount;
-  g_ctx.lds_per_block = prop.sharedMemPerBlock;
-  g_ctx.ready = true;
-  return RT_OK;
-}
-
-void rt_shutdown(void) { g_ctx.ready = false; }
-
-void rt_scene_destroy(rt_scene *s) {
+static void replica_destroy(Replica *s) {
   if (!s) return;
+  (void)hipSetDevice(s->device);
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
   (void)hipFree(s->d_fnodes32); (void)hipFree(s->d_fprims); (void)hipFree(s->d_ref_anc); (void)hipFree(s->d_ref_depth); (void)hipFree(s->d_leaf_anc);
   (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky);
-  (void)hipFree(s->d_counter); (void)hipFree(s->d_stats); (void)hipFree(s->d_fscratch); (void)hipFree(s->d_samples);
-  (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_tiles);
+  (void)hipFree(s->ws.counter); (void)hipFree(s->ws.stats); (void)hipFree(s->ws.fscratch); (void)hipFree(s->ws.samples); (void)hipFree(s->ws.tiles);
+  (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
+  (void)hipFree(s->p_color); (void)hipFree(s->p_radiance); (void)hipFree(s->p_primid); (void)hipFree(s->p_rgb8);
+  if (s->g_color != s->p_color) (void)hipFree(s->g_color);
+  if (s->g_radiance != s->p_radiance) (void)hipFree(s->g_radiance);
+  if (s->g_primid != s->p_primid) (void)hipFree(s->g_primid);
+  if (s->g_rgb8 != s->p_rgb8) (void)hipFree(s->g_rgb8);
   for (hipEvent_t e : s->kt_events) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 
-int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
-  if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
-  *out = nullptr;
-  int rc = ensure_init();
-  if (rc) return rc;
+// Validates the descriptor and lays the scene out for the kernels (host memory only).
+static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
+  int rc;
   if (d->n_nodes <= 0 || d->n_prims <= 0) return fail(RT_ERR_EMPTY_SCENE, "empty scene: Cannot compute bounding box of empty list");
   if (!d->node_bounds || !d->node_child || !d->prim_kind || !d->prim_data || !d->prim_material)
     return fail(RT_ERR_INVALID, "scene descriptor has null arrays");
@@ -177,7 +210,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   if (d->sky_format != RT_SKY_NONE && (d->sky_width <= 0 || d->sky_height <= 0 || !d->sky_pixels))
     return fail(RT_ERR_INVALID, "bad sky texture");
   if (d->sky_format < RT_SKY_NONE || d->sky_format > RT_SKY_RGBF) return fail(RT_ERR_INVALID, "bad sky format");
-
+  if (d->bg_kind != RT_BG_GRADIENT && d->bg_kind != RT_BG_SOLID) return fail(RT_ERR_INVALID, "unknown background kind");
   const int nn = d->n_nodes, np = d->n_prims;
   const bool dbg_t = getenv("RT_DEBUG") != nullptr;          // RT_DEBUG: where the set-up time goes
   auto t_last = std::chrono::steady_clock::now();
@@ -241,13 +274,13 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   if (depth > 60) return fail(RT_ERR_UNSUPPORTED, "BVH depth %d exceeds the traversal stack limit (60)", depth);
 
   lap("validate + order ref nodes");
-  auto *s = new rt_scene();
-  s->device = g_ctx.device;
+  HostScene *s = &hs;
   s->depth = depth;
   s->n_internal = (int)order.size();
 
   // ---- materials: dense table, index 0 = defaultMaterial (Rendering/Material.hs:25-35)
-  std::vector<DMaterial> mats(1 + d->n_materials);
+  std::vector<DMaterial> &mats = hs.mats;
+  mats.assign(1 + d->n_materials, DMaterial());
   auto set_mat = [](DMaterial &m, const rt_material *src) {
     std::memset(&m, 0, sizeof m);
     if (!src) { m.diffuse[0] = m.diffuse[1] = m.diffuse[2] = 1.0; return; }
@@ -273,13 +306,15 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   const int n_host_threads = host_threads();
 
   // ---- primitives (leaf order is kept: it decides ties) + the FP64 leaf boxes planes need
-  std::vector<DPrim> prims(np);
-  std::vector<int32_t> pids(np);
-  std::vector<double> plane_boxes;
+  std::vector<DPrim> &prims = hs.prims;
+  std::vector<int32_t> &pids = hs.pids;
+  std::vector<double> &plane_boxes = hs.plane_boxes;
+  prims.assign(np, DPrim()); pids.assign(np, 0); plane_boxes.clear();
   // Per triangle: the face normal the reference recomputes at every hit, normalize(e1 x e2) (Triangle.hs:51), and the
   // re-normalisation computeLighting applies to it (Light.hs:19).  Same operations in the same order as the device
   // helpers cross3 / dot3 / normalize3 (rt_device.h), IEEE sqrt and division, no contraction: bit-identical values.
-  std::vector<double> tri_normals((size_t)np * 6, 0.0);
+  std::vector<double> &tri_normals = hs.tri_normals;
+  tri_normals.assign((size_t)np * 6, 0.0);
   auto normalize_like_device = [](const double v[3], double out[3]) {
     const double s = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     out[0] = s * v[0]; out[1] = s * v[1]; out[2] = s * v[2];
@@ -312,7 +347,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
       pids[i] = d->prim_id ? d->prim_id[i] : (int32_t)i;
     }
   });
-  if (bad_prim.load() >= 0) { const int i = bad_prim.load(); delete s; return fail(RT_ERR_INVALID, "primitive %d has unknown kind %d", i, d->prim_kind[i]); }
+  if (bad_prim.load() >= 0) { const int i = bad_prim.load(); return fail(RT_ERR_INVALID, "primitive %d has unknown kind %d", i, d->prim_kind[i]); }
   lap("primitives + normals");
   // leaves: mark the last primitive, give planes their leaf box
   std::vector<char> in_leaf(np, 0);
@@ -321,7 +356,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     long first = -1L - d->node_child[2 * i], cnt = d->node_child[2 * i + 1];
     prims[first + cnt - 1].kind |= DPRIM_LAST;
     for (long k = first; k < first + cnt; ++k) {
-      if (in_leaf[k]) { delete s; return fail(RT_ERR_INVALID, "primitive %ld belongs to two leaves", k); }
+      if (in_leaf[k]) { return fail(RT_ERR_INVALID, "primitive %ld belongs to two leaves", k); }
       in_leaf[k] = 1;
       if ((prims[k].kind & DPRIM_KIND_MASK) == RT_PRIM_PLANE && i != 0) {   // the root's own box is never tested (BVH.hs:123)
         prims[k].d[6] = (double)(plane_boxes.size() / 6);
@@ -330,17 +365,19 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
   }
   for (int i = 0; i < np; ++i)
-    if (!in_leaf[i]) { delete s; return fail(RT_ERR_INVALID, "primitive %d belongs to no leaf of the tree", i); }
+    if (!in_leaf[i]) { return fail(RT_ERR_INVALID, "primitive %d belongs to no leaf of the tree", i); }
   for (int q = 0; q < 6; ++q) maxabs = std::max(maxabs, std::fabs(d->node_bounds[q]));
 
   // ---- internal nodes: children's boxes, FP64 as given and FP32 rounded outward
   const int ni = std::max(1, s->n_internal);
-  std::vector<DNode<float>> n32(ni);
-  std::vector<DNode<double>> n64(ni);
+  std::vector<DNode<float>> &n32 = hs.n32;
+  std::vector<DNode<double>> &n64 = hs.n64;
+  n32.resize(ni); n64.resize(ni);
   std::memset(n32.data(), 0, ni * sizeof(DNode<float>));
   std::memset(n64.data(), 0, ni * sizeof(DNode<double>));
   // where each internal node and each primitive hangs in the reference tree (the fast tree's tie rule climbs these)
-  std::vector<int32_t> ref_anc(ni, -1), ref_depth(ni, 0), leaf_anc(np, 0);
+  std::vector<int32_t> &ref_anc = hs.ref_anc, &ref_depth = hs.ref_depth, &leaf_anc = hs.leaf_anc;
+  ref_anc.assign(ni, -1); ref_depth.assign(ni, 0); leaf_anc.assign(np, 0);
   auto ref_of = [&](int child) -> int32_t { return is_leaf(child) ? d->node_child[2 * child] : dev_index[child]; };   // leaf: -1-first == ~first
   for (int k = 0; k < s->n_internal; ++k) {
     int i = order[k];
@@ -369,8 +406,9 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   //      (vertex extent padded by 1e-8), spheres as Sphere.hs:20-22, planes by the box of their reference leaf -
   //      the only region where the reference can see them (Plane.hs:20).
   FastBvh fb;
-  std::vector<DNode<float>> fn32(1);
-  std::vector<DPrim> fprims;
+  std::vector<DNode<float>> &fn32 = hs.fn32;
+  std::vector<DPrim> &fprims = hs.fprims;
+  fn32.resize(1); fprims.clear();
   std::memset(fn32.data(), 0, sizeof(DNode<float>));
   bool fast_ok = !is_leaf(0);
   if (fast_ok) {
@@ -457,57 +495,148 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   s->has_fast = fast_ok;
   lap("fast tree order + prims");
 
-  std::vector<DLight> lights(std::max(1, d->n_lights));
+  std::vector<DLight> &lights = hs.lights;
+  lights.resize(std::max(1, d->n_lights));
   std::memset(lights.data(), 0, lights.size() * sizeof(DLight));
   for (int i = 0; i < d->n_lights; ++i) {
-    if (d->lights[i].kind != RT_LIGHT_POINT && d->lights[i].kind != RT_LIGHT_DIRECTIONAL) { delete s; return fail(RT_ERR_INVALID, "light %d has unknown kind", i); }
+    if (d->lights[i].kind != RT_LIGHT_POINT && d->lights[i].kind != RT_LIGHT_DIRECTIONAL) { return fail(RT_ERR_INVALID, "light %d has unknown kind", i); }
     for (int k = 0; k < 3; ++k) { lights[i].vec[k] = d->lights[i].vec[k]; lights[i].intensity[k] = d->lights[i].intensity[k]; }
     lights[i].kind = d->lights[i].kind;
   }
 
-#define UP(call) do { if ((rc = (call))) { rt_scene_destroy(s); return rc; } } while (0)
-  UP(dev_upload(&s->d_nodes32, n32.data(), (size_t)ni));
-  UP(dev_upload(&s->d_nodes64, n64.data(), (size_t)ni));
-  if (fast_ok) {
-    UP(dev_upload(&s->d_fnodes32, fn32.data(), fn32.size()));
-    UP(dev_upload(&s->d_fprims, fprims.data(), fprims.size()));
-    UP(dev_upload(&s->d_ref_anc, ref_anc.data(), ref_anc.size()));
-    UP(dev_upload(&s->d_ref_depth, ref_depth.data(), ref_depth.size()));
-    UP(dev_upload(&s->d_leaf_anc, leaf_anc.data(), leaf_anc.size()));
-  }
-  UP(dev_upload(&s->d_prims, prims.data(), (size_t)np));
-  UP(dev_upload(&s->d_prim_ids, pids.data(), (size_t)np));
-  UP(dev_upload(&s->d_mats, mats.data(), mats.size()));
-  UP(dev_upload(&s->d_lights, lights.data(), lights.size()));
-  UP(dev_upload(&s->d_plane_boxes, plane_boxes.data(), plane_boxes.size()));
-  UP(dev_upload(&s->d_tri_normals, tri_normals.data(), tri_normals.size()));
-  if (d->sky_format != RT_SKY_NONE) {
-    size_t bytes = (size_t)d->sky_width * d->sky_height * 3 * (d->sky_format == RT_SKY_RGB8 ? 1 : 4);
-    uint8_t *p = nullptr;
-    UP(dev_upload(&p, (const uint8_t *)d->sky_pixels, bytes));
-    s->d_sky = p;
-  }
-  uint32_t zero = 0;
-  UP(dev_upload(&s->d_counter, &zero, 1));
-  unsigned long long zs[STAT_COUNT] = {0};
-  UP(dev_upload(&s->d_stats, zs, STAT_COUNT));
-#undef UP
-  lap("uploads");
-  if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
 
-  KScene &k = s->ks;
-  k.nodes = s->d_nodes32; k.prims = s->d_prims; k.tprims = s->d_prims;
-  k.ref_nodes64 = s->d_nodes64; k.ref_anc = s->d_ref_anc; k.ref_depth = s->d_ref_depth; k.leaf_anc = s->d_leaf_anc;
-  k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
-  k.plane_boxes = s->d_plane_boxes; k.tri_normals = s->d_tri_normals; k.sky = s->d_sky;
+  hs.sky = d->sky_pixels;
+  hs.sky_bytes = d->sky_format == RT_SKY_NONE ? 0 : (size_t)d->sky_width * d->sky_height * 3 * (d->sky_format == RT_SKY_RGB8 ? 1 : 4);
+  KScene &k = hs.ks;
   k.root_ref = is_leaf(0) ? d->node_child[0] : 0;
   k.ref_root_ref = k.root_ref;
-  s->has_boxed_planes = !plane_boxes.empty();
   k.n_lights = d->n_lights;
   k.bg_kind = d->bg_kind; k.sky_format = d->sky_format; k.sky_w = d->sky_width; k.sky_h = d->sky_height;
   for (int q = 0; q < 3; ++q) { k.bg1[q] = d->bg_color1[q]; k.bg2[q] = d->bg_color2[q]; }
   k.rscene = f32_up(maxabs);
-  if (d->bg_kind != RT_BG_GRADIENT && d->bg_kind != RT_BG_SOLID) { rt_scene_destroy(s); return fail(RT_ERR_INVALID, "unknown background kind"); }
+  lap("lights + scalars");
+  return RT_OK;
+}
+
+// Copies a prepared scene to the CURRENT device.
+static int upload_replica(const HostScene &hs, int device, Replica **out) {
+  int rc;
+  auto *s = new Replica();
+  s->device = device;
+  s->depth = hs.depth; s->n_internal = hs.n_internal;
+  s->has_fast = hs.has_fast; s->f_internal = hs.f_internal; s->f_depth = hs.f_depth; s->f_root_ref = hs.f_root_ref;
+  s->has_boxed_planes = !hs.plane_boxes.empty();
+#define UP(call) do { if ((rc = (call))) { replica_destroy(s); return rc; } } while (0)
+  UP(dev_upload(&s->d_nodes32, hs.n32.data(), hs.n32.size()));
+  UP(dev_upload(&s->d_nodes64, hs.n64.data(), hs.n64.size()));
+  if (hs.has_fast) {
+    UP(dev_upload(&s->d_fnodes32, hs.fn32.data(), hs.fn32.size()));
+    UP(dev_upload(&s->d_fprims, hs.fprims.data(), hs.fprims.size()));
+    UP(dev_upload(&s->d_ref_anc, hs.ref_anc.data(), hs.ref_anc.size()));
+    UP(dev_upload(&s->d_ref_depth, hs.ref_depth.data(), hs.ref_depth.size()));
+    UP(dev_upload(&s->d_leaf_anc, hs.leaf_anc.data(), hs.leaf_anc.size()));
+  }
+  UP(dev_upload(&s->d_prims, hs.prims.data(), hs.prims.size()));
+  UP(dev_upload(&s->d_prim_ids, hs.pids.data(), hs.pids.size()));
+  UP(dev_upload(&s->d_mats, hs.mats.data(), hs.mats.size()));
+  UP(dev_upload(&s->d_lights, hs.lights.data(), hs.lights.size()));
+  UP(dev_upload(&s->d_plane_boxes, hs.plane_boxes.data(), hs.plane_boxes.size()));
+  UP(dev_upload(&s->d_tri_normals, hs.tri_normals.data(), hs.tri_normals.size()));
+  if (hs.sky_bytes) {
+    uint8_t *p = nullptr;
+    UP(dev_upload(&p, (const uint8_t *)hs.sky, hs.sky_bytes));
+    s->d_sky = p;
+  }
+  uint32_t zero = 0;
+  UP(dev_upload(&s->ws.counter, &zero, 1));
+  unsigned long long zs[STAT_COUNT] = {0};
+  UP(dev_upload(&s->ws.stats, zs, STAT_COUNT));
+#undef UP
+  if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { replica_destroy(s); return fail(RT_ERR_HIP, "hipEventCreate failed"); }
+  KScene &k = s->ks;
+  k = hs.ks;
+  k.nodes = s->d_nodes32; k.prims = s->d_prims; k.tprims = s->d_prims;
+  k.ref_nodes64 = s->d_nodes64; k.ref_anc = s->d_ref_anc; k.ref_depth = s->d_ref_depth; k.leaf_anc = s->d_leaf_anc;
+  k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
+  k.plane_boxes = s->d_plane_boxes; k.tri_normals = s->d_tri_normals; k.sky = s->d_sky;
+  *out = s;
+  return RT_OK;
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int rt_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render core has no CPU fallback");
+  if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+  if (device >= n || device >= RT_MAX_DEVICES) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  int rc = init_device(device);
+  if (rc) return rc;
+  g_group.assign(1, device);
+  return RT_OK;
+}
+
+int rt_init_devices(int32_t n_devices, const int32_t *devices) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device visible: the render core has no CPU fallback");
+  if (n_devices == 0 && !devices) n_devices = n;             // 0 = all visible devices
+  if (n_devices <= 0 || n_devices > RT_MAX_DEVICES) return fail(RT_ERR_INVALID, "bad device count %d", (int)n_devices);
+  std::vector<int> group(n_devices);
+  for (int i = 0; i < n_devices; ++i) {
+    group[i] = devices ? devices[i] : i;
+    if (group[i] < 0 || group[i] >= n) return fail(RT_ERR_INVALID, "device %d out of range (%d visible)", group[i], n);
+  }
+  for (int i = n_devices - 1; i >= 0; --i) {                 // ends with the group's device 0 current
+    HIP_TRY(hipSetDevice(group[i]));
+    int rc = init_device(group[i]);
+    if (rc) return rc;
+    if (group[i] != group[0]) {                              // let the packed tiles go to device 0 directly over xGMI
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, group[i], group[0]) == hipSuccess && can) {
+        hipError_t e = hipDeviceEnablePeerAccess(group[0], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // the copy then stages through the host
+        else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      }
+    }
+  }
+  g_group = group;
+  return RT_OK;
+}
+
+int rt_device_count(void) { return (int)g_group.size(); }
+
+void rt_shutdown(void) { g_group.clear(); }
+
+void rt_scene_destroy(rt_scene *s) {
+  if (!s) return;
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  for (Replica *r : s->rep) replica_destroy(r);
+  if (have_cur) (void)hipSetDevice(cur);
+  delete s;
+}
+
+int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
+  if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int rc = ensure_init();
+  if (rc) return rc;
+  HostScene hs;
+  if ((rc = prepare_host_scene(d, hs))) return rc;
+  auto *s = new rt_scene();
+  const std::vector<int> group = g_group.empty() ? std::vector<int>{0} : g_group;
+  for (size_t i = group.size(); i-- > 0;) {                  // device 0 of the group last: it stays current
+    Replica *r = nullptr;
+    if (hipSetDevice(group[i]) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, "hipSetDevice(%d) failed", group[i]); }
+    if ((rc = upload_replica(hs, group[i], &r))) { rt_scene_destroy(s); return rc; }
+    s->rep.insert(s->rep.begin(), r);
+  }
   *out = s;
   return RT_OK;
 }
@@ -530,8 +659,7 @@ int rt_fast_bvh_build(int32_t n_prims, const double *boxes, int32_t max_leaf, in
 int rt_tile_count(int32_t W, int32_t H, int32_t rank, int32_t world) {
   if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad tile query");
   int tx = tiles_x_of(W), ty = tiles_y_of(H), n = 0;
-  for (int y = 0; y < ty; ++y)
-    for (int x = 0; x < tx; ++x) n += ((x + y) % world) == rank;
+  for (int y = 0; y < ty; ++y) n += tiles_in_row(tx, y, rank, world);
   return n;
 }
 
@@ -547,7 +675,7 @@ int rt_tile_list(int32_t W, int32_t H, int32_t rank, int32_t world, int32_t *til
 }  // extern "C"
 
 static int check_frame(const rt_scene *s, const rt_camera *cam, const rt_params *p) {
-  if (!s || !cam || !p) return fail(RT_ERR_INVALID, "null argument");
+  if (!s || s->rep.empty() || !cam || !p) return fail(RT_ERR_INVALID, "null argument");
   if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_bounces < 0)
     return fail(RT_ERR_INVALID, "bad image/raytracer settings");
   if ((long long)p->width * p->height >= (1LL << 31)) return fail(RT_ERR_UNSUPPORTED, "image too large");
@@ -556,16 +684,25 @@ static int check_frame(const rt_scene *s, const rt_camera *cam, const rt_params 
   return RT_OK;
 }
 
-static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
-  if (s->tl_w == W && s->tl_h == H && s->tl_rank == rank && s->tl_world == world) return RT_OK;
-  int n = rt_tile_count(W, H, rank, world);
+// This rank's tile list, written on the device by k_make_tiles (no host list, no copy).  A growable workspace enlarges
+// its buffer on demand; a fixed one refuses frames with more tiles than it holds.
+static int ensure_tiles(Workspace &ws, int W, int H, int rank, int world, hipStream_t stream) {
+  if (ws.tl_w == W && ws.tl_h == H && ws.tl_rank == rank && ws.tl_world == world && !ws.fixed) return RT_OK;
+  const int n = rt_tile_count(W, H, rank, world);
   if (n < 0) return n;
-  std::vector<int32_t> t(std::max(1, n));
-  rt_tile_list(W, H, rank, world, t.data());
-  (void)hipFree(s->d_tiles); s->d_tiles = nullptr;
-  int rc = dev_upload(&s->d_tiles, t.data(), t.size());
-  if (rc) return rc;
-  s->tl_w = W; s->tl_h = H; s->tl_rank = rank; s->tl_world = world; s->tl_n = n;
+  if ((size_t)n > ws.tiles_cap) {
+    if (ws.fixed) return fail(RT_ERR_UNSUPPORTED, "%d tiles exceed the %zu the static scratch holds", n, ws.tiles_cap);
+    HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(ws.tiles); ws.tiles = nullptr; ws.tiles_cap = 0;
+    if (hipMalloc((void **)&ws.tiles, (size_t)n * sizeof(int32_t)) != hipSuccess) return fail(RT_ERR_OOM, "tile list of %d entries", n);
+    ws.tiles_cap = (size_t)n;
+  }
+  const int ty = tiles_y_of(H);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_make_tiles, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, stream, tiles_x_of(W), ty, rank, world, ws.tiles);
+    HIP_TRY(hipGetLastError());
+  }
+  ws.tl_w = W; ws.tl_h = H; ws.tl_rank = rank; ws.tl_world = world; ws.tl_n = n;
   return RT_OK;
 }
 
@@ -573,8 +710,9 @@ static int ensure_tiles(rt_scene *s, int W, int H, int rank, int world) {
 // range of the rank's tiles whose per-path radiance fits the sample buffer; normally that is the whole frame
 // (1080p x 100 spp: 5 GB of 288 GB).  The split never changes a result: k_resolve sums in sample order.
 template <typename BT, bool STATS, bool FAST>
-static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
+static int launch_kernel(Replica *s, Workspace &ws, const KFrame &fr_in, hipStream_t stream) {
   KFrame fr = fr_in;
+  const DevCtx &dc = g_dev[s->device];
   const int n_internal = FAST ? s->f_internal : s->n_internal;
   fr.stack_depth = std::max(1, FAST ? s->f_depth : s->depth) + 1;
   // One workgroup per CU, RT_MIN_WAVES waves per SIMD; deep trees (long per-lane stacks) get fewer waves so that the
@@ -613,39 +751,52 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
 
   // tiles per launch from the sample-buffer budget
   const size_t bytes_per_tile = (size_t)64 * fr.spp * 3 * sizeof(double);
-  const size_t max_tiles_32 = (size_t)0x7fffffff / ((size_t)64 * fr.spp);     // item indices are 32-bit
+  const size_t max_tiles_32 = (size_t)0x7fffffff / ((size_t)64 * fr.spp);     // item indices are 32-bit: larger frames take several launches
   if (max_tiles_32 == 0) return fail(RT_ERR_UNSUPPORTED, "samplesPerPixel %d too large", fr.spp);
   size_t tpp = std::min<size_t>((size_t)fr.n_tiles, max_tiles_32);
-  if (tpp * bytes_per_tile > s->samples_cap) {
-    size_t budget;
-    if (const char *env = getenv("RT_SAMPLE_BUDGET_MB")) budget = (size_t)atol(env) << 20;   // tests: forces several launches
-    else {
-      size_t fre = 0, tot = 0;
-      HIP_TRY(hipMemGetInfo(&fre, &tot));
-      budget = std::min<size_t>((fre + s->samples_cap) / 2, (size_t)64 << 30);
-    }
-    tpp = std::max<size_t>(1, std::min(tpp, budget / bytes_per_tile));
-    if (tpp * bytes_per_tile > s->samples_cap) {            // grows only on the first launch / a larger frame
-      HIP_TRY(hipStreamSynchronize(stream));
-      (void)hipFree(s->d_samples); s->d_samples = nullptr; s->samples_cap = 0;
-      if (hipMalloc((void **)&s->d_samples, tpp * bytes_per_tile) != hipSuccess)
-        return fail(RT_ERR_OOM, "sample buffer of %zu bytes (%zu tiles x %d spp)", tpp * bytes_per_tile, tpp, fr.spp);
-      s->samples_cap = tpp * bytes_per_tile;
+  if (tpp * bytes_per_tile > ws.samples_cap) {
+    if (ws.fixed) {
+      tpp = ws.samples_cap / bytes_per_tile;
+      if (tpp == 0) return fail(RT_ERR_UNSUPPORTED, "samplesPerPixel %d: one tile's samples (%zu bytes) exceed the static scratch (%zu)", fr.spp, bytes_per_tile, ws.samples_cap);
+    } else {
+      size_t budget;
+      if (const char *env = getenv("RT_SAMPLE_BUDGET_MB")) budget = (size_t)atol(env) << 20;   // tests: forces several launches
+      else {
+        size_t fre = 0, tot = 0;
+        HIP_TRY(hipMemGetInfo(&fre, &tot));
+        budget = std::min<size_t>((fre + ws.samples_cap) / 2, (size_t)64 << 30);
+      }
+      tpp = std::max<size_t>(1, std::min(tpp, budget / bytes_per_tile));
+      if (tpp * bytes_per_tile > ws.samples_cap) {            // grows only on the first launch / a larger frame
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(ws.samples); ws.samples = nullptr; ws.samples_cap = 0;
+        if (hipMalloc((void **)&ws.samples, tpp * bytes_per_tile) != hipSuccess)
+          return fail(RT_ERR_OOM, "sample buffer of %zu bytes (%zu tiles x %d spp)", tpp * bytes_per_tile, tpp, fr.spp);
+        ws.samples_cap = tpp * bytes_per_tile;
+      }
     }
   }
-  fr.samples = s->d_samples;
+  fr.samples = ws.samples;
 
   const size_t waves_first = (tpp * 64 * (size_t)fr.spp + 63) / 64;           // wave-loads of items in the largest launch
-  const int grid_max = (int)std::max<size_t>(1, std::min<size_t>((waves_first + wpb - 1) / wpb, (size_t)g_ctx.n_cu * per_cu));
-  const size_t waves = (size_t)grid_max * wpb;
-  if (waves > s->fscratch_waves || fr.scratch_rows > s->fscratch_rows) {      // grows only on the first launch / a larger grid; never inside a steady-state loop
-    HIP_TRY(hipStreamSynchronize(stream));
-    (void)hipFree(s->d_fscratch); s->d_fscratch = nullptr; s->fscratch_waves = 0;
-    if (hipMalloc((void **)&s->d_fscratch, waves * fr.scratch_rows * 64 * sizeof(double)) != hipSuccess) return fail(RT_ERR_OOM, "path records for %zu waves", waves);
-    s->fscratch_waves = waves; s->fscratch_rows = fr.scratch_rows;
+  int grid_max = (int)std::max<size_t>(1, std::min<size_t>((waves_first + wpb - 1) / wpb, (size_t)dc.n_cu * per_cu));
+  const size_t bytes_per_wave = (size_t)fr.scratch_rows * 64 * sizeof(double);
+  if ((size_t)grid_max * wpb * bytes_per_wave > ws.fscratch_cap) {
+    if (ws.fixed) {                                          // fewer resident workgroups: still correct, the static scratch just holds fewer records
+      grid_max = (int)std::min<size_t>((size_t)grid_max, ws.fscratch_cap / ((size_t)wpb * bytes_per_wave));
+      if (grid_max < 1) return fail(RT_ERR_UNSUPPORTED, "BVH depth %d: one workgroup's path records (%zu bytes) exceed the static scratch (%zu)",
+                                    fr.stack_depth, (size_t)wpb * bytes_per_wave, ws.fscratch_cap);
+    } else {                                                 // grows only on the first launch / a larger grid; never inside a steady-state loop
+      HIP_TRY(hipStreamSynchronize(stream));
+      (void)hipFree(ws.fscratch); ws.fscratch = nullptr; ws.fscratch_cap = 0;
+      const size_t want = (size_t)grid_max * wpb * bytes_per_wave;
+      if (hipMalloc((void **)&ws.fscratch, want) != hipSuccess) return fail(RT_ERR_OOM, "path records for %zu waves", (size_t)grid_max * wpb);
+      ws.fscratch_cap = want;
+    }
   }
-  fr.fscratch = s->d_fscratch;
-  if (STATS) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
+  fr.fscratch = ws.fscratch;
+  fr.tile_counter = ws.counter; fr.stats = ws.stats;
+  if (STATS) HIP_TRY(hipMemsetAsync(ws.stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
   KScene ks = s->ks;
   if (sizeof(BT) == 8) ks.nodes = s->d_nodes64;
   if (FAST) { ks.nodes = s->d_fnodes32; ks.tprims = s->d_fprims; ks.root_ref = s->f_root_ref; }
@@ -664,8 +815,8 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
     }
     const size_t want = ((size_t)fr.n_items / 64 + wpb - 1) / wpb;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>(want, (size_t)grid_max));
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, sizeof(uint32_t), stream));
-    const bool timed = s->kt_pending < rt_scene::KT_RING;
+    HIP_TRY(hipMemsetAsync(ws.counter, 0, sizeof(uint32_t), stream));
+    const bool timed = !ws.fixed && s->kt_pending < Replica::KT_RING;      // (creating an event allocates: not on the fixed workspace)
     if (timed) {
       while ((int)s->kt_events.size() < 2 * (s->kt_pending + 1)) {
         hipEvent_t e;
@@ -677,7 +828,7 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
 #ifdef RT_TIMERS
     static unsigned long long *d_dbg = nullptr;            // experiment build: per-wave timeline, dumped to $RT_WAVE_DUMP after each launch
     const char *dump = getenv("RT_WAVE_DUMP");
-    if (dump && !d_dbg) HIP_TRY(hipMalloc((void **)&d_dbg, ((size_t)g_ctx.n_cu * 64 * 4 + 2 * 262144) * sizeof(unsigned long long)));
+    if (dump && !d_dbg) HIP_TRY(hipMalloc((void **)&d_dbg, ((size_t)dc.n_cu * 64 * 4 + 2 * 262144) * sizeof(unsigned long long)));
     fr.dbg = dump ? d_dbg : nullptr;
     if (dump) HIP_TRY(hipMemsetAsync(d_dbg, 0, ((size_t)grid * wpb * 4 + 2 * 262144) * sizeof(unsigned long long), stream));
 #endif
@@ -697,7 +848,7 @@ static int launch_kernel(rt_scene *s, const KFrame &fr_in, hipStream_t stream) {
   return RT_OK;
 }
 
-static int launch_render(rt_scene *s, const rt_camera *cam, const rt_params *p, int rank, int world, bool packed,
+static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const rt_params *p, int rank, int world, bool packed,
                          double *d_color, double *d_radiance, int32_t *d_primid, hipStream_t stream) {
   int rc;
   KFrame fr{};
@@ -706,38 +857,37 @@ static int launch_render(rt_scene *s, const rt_camera *cam, const rt_params *p, 
   fr.exposure = p->exposure; fr.gamma = p->gamma;
   fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
   fr.tiles_x = tiles_x_of(p->width);
-  if (world > 1 || packed) {
-    if ((rc = ensure_tiles(s, p->width, p->height, rank, world))) return rc;
-    fr.tiles = s->d_tiles; fr.n_tiles = s->tl_n;
-  } else {
+  if (world > 1) {
+    if ((rc = ensure_tiles(ws, p->width, p->height, rank, world, stream))) return rc;
+    fr.tiles = ws.tiles; fr.n_tiles = ws.tl_n;
+  } else {                                                   // one rank: its tile list is 0, 1, 2, ... - no list needed
     fr.tiles = nullptr; fr.n_tiles = fr.tiles_x * tiles_y_of(p->height);
   }
   fr.packed = packed ? 1 : 0;
   fr.out_color = d_color; fr.out_radiance = d_radiance; fr.out_primid = d_primid;
-  fr.tile_counter = s->d_counter; fr.stats = s->d_stats;
   if (fr.n_tiles == 0) return RT_OK;
 #ifdef RT_TIMERS
   const bool st = false;                                    // experiment build: collect_stats times the bodies of the TIMED variant
-  if (p->collect_stats) HIP_TRY(hipMemsetAsync(s->d_stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
+  if (p->collect_stats) HIP_TRY(hipMemsetAsync(ws.stats, 0, STAT_COUNT * sizeof(unsigned long long), stream));
 #else
   const bool st = p->collect_stats != 0;
 #endif
-  if (p->box_precision == 1) return st ? launch_kernel<double, true, false>(s, fr, stream) : launch_kernel<double, false, false>(s, fr, stream);
-  if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, fr, stream) : launch_kernel<float, false, true>(s, fr, stream);
-  return st ? launch_kernel<float, true, false>(s, fr, stream) : launch_kernel<float, false, false>(s, fr, stream);
+  if (p->box_precision == 1) return st ? launch_kernel<double, true, false>(s, ws, fr, stream) : launch_kernel<double, false, false>(s, ws, fr, stream);
+  if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true>(s, ws, fr, stream);
+  return st ? launch_kernel<float, true, false>(s, ws, fr, stream) : launch_kernel<float, false, false>(s, ws, fr, stream);
 }
 
-static int read_stats(rt_scene *s, rt_stats *st) {
+static int read_stats(const Workspace &ws, rt_stats *st) {   // ADDS this workspace's counters to *st
   unsigned long long h[STAT_COUNT];
-  HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
-  st->rays_closest = h[STAT_CLOSEST]; st->rays_shadow = h[STAT_SHADOW]; st->nodes_visited = h[STAT_NODES];
-  st->tri_tests = h[STAT_TRI]; st->sphere_tests = h[STAT_SPHERE]; st->plane_tests = h[STAT_PLANE]; st->shaded_hits = h[STAT_SHADED];
-  st->sched_node_steps = h[STAT_IT_NODE] / 64; st->sched_prim_steps = h[STAT_IT_PRIM] / 64; st->sched_shade_steps = h[STAT_IT_SHADE] / 64;
-  st->sched_live_lanes = h[STAT_LIVE];
-  st->top_node_hits = h[STAT_TOPHIT];
-  st->rays_shadow_culled = h[STAT_SHADOW_CULLED];
-  st->rays_literal = h[STAT_LITERAL];
-  st->cyc_vote = h[STAT_T_VOTE]; st->cyc_node = h[STAT_T_NODE]; st->cyc_prim = h[STAT_T_PRIM]; st->cyc_shade = h[STAT_T_SHADE]; st->cyc_refill = h[STAT_T_REFILL];
+  HIP_TRY(hipMemcpy(h, ws.stats, sizeof h, hipMemcpyDeviceToHost));
+  st->rays_closest += h[STAT_CLOSEST]; st->rays_shadow += h[STAT_SHADOW]; st->nodes_visited += h[STAT_NODES];
+  st->tri_tests += h[STAT_TRI]; st->sphere_tests += h[STAT_SPHERE]; st->plane_tests += h[STAT_PLANE]; st->shaded_hits += h[STAT_SHADED];
+  st->sched_node_steps += h[STAT_IT_NODE] / 64; st->sched_prim_steps += h[STAT_IT_PRIM] / 64; st->sched_shade_steps += h[STAT_IT_SHADE] / 64;
+  st->sched_live_lanes += h[STAT_LIVE];
+  st->top_node_hits += h[STAT_TOPHIT];
+  st->rays_shadow_culled += h[STAT_SHADOW_CULLED];
+  st->rays_literal += h[STAT_LITERAL];
+  st->cyc_vote += h[STAT_T_VOTE]; st->cyc_node += h[STAT_T_NODE]; st->cyc_prim += h[STAT_T_PRIM]; st->cyc_shade += h[STAT_T_SHADE]; st->cyc_refill += h[STAT_T_REFILL];
   return RT_OK;
 }
 
@@ -745,7 +895,7 @@ static int read_stats(rt_scene *s, rt_stats *st) {
 struct TileCacheEntry { int device, W, H, rank, world, n; int32_t *d_tiles; };
 static std::vector<TileCacheEntry> g_tile_cache;
 static std::mutex g_tile_mu;
-static int cached_tiles(int W, int H, int rank, int world, const int32_t **d_tiles, int *n) {
+static int cached_tiles(int W, int H, int rank, int world, const int32_t **d_tiles, int *n, hipStream_t stream) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> g(g_tile_mu);
@@ -753,36 +903,56 @@ static int cached_tiles(int W, int H, int rank, int world, const int32_t **d_til
     if (e.device == dev && e.W == W && e.H == H && e.rank == rank && e.world == world) { *d_tiles = e.d_tiles; *n = e.n; return RT_OK; }
   int cnt = rt_tile_count(W, H, rank, world);
   if (cnt < 0) return cnt;
-  std::vector<int32_t> t(std::max(1, cnt));
-  rt_tile_list(W, H, rank, world, t.data());
   int32_t *d = nullptr;
-  int rc = dev_upload(&d, t.data(), t.size());   // synchronous copy: t may die afterwards
-  if (rc) return rc;
+  if (hipMalloc((void **)&d, (size_t)std::max(1, cnt) * sizeof(int32_t)) != hipSuccess) return fail(RT_ERR_OOM, "tile list of %d entries", cnt);
+  if (cnt > 0) {
+    const int ty = tiles_y_of(H);
+    hipLaunchKernelGGL(k_make_tiles, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, stream, tiles_x_of(W), ty, rank, world, d);
+    HIP_TRY(hipGetLastError());
+    if (stream != nullptr) HIP_TRY(hipStreamSynchronize(stream));   // later callers may use another stream
+    else HIP_TRY(hipDeviceSynchronize());
+  }
   g_tile_cache.push_back({dev, W, H, rank, world, cnt, d});
   *d_tiles = d; *n = cnt;
   return RT_OK;
 }
 
-extern "C" {
+static int untile_launch(int W, int H, int rank, int world, const void *d_packed, void *d_image, int n_comp, bool bytes, hipStream_t stream) {
+  int n = 0, rc;
+  const int32_t *d_t = nullptr;
+  if ((rc = cached_tiles(W, H, rank, world, &d_t, &n, stream))) return rc;
+  if (n == 0) return RT_OK;
+  const size_t slots = (size_t)n * 64;
+  if (bytes)
+    hipLaunchKernelGGL(k_untile_bytes, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream,
+                       d_t, n, tiles_x_of(W), W, H, n_comp, (const uint8_t *)d_packed, (uint8_t *)d_image);
+  else
+    hipLaunchKernelGGL(k_untile, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream,
+                       d_t, n, tiles_x_of(W), W, H, n_comp, (const double *)d_packed, (double *)d_image);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
 
-int rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
-  int rc = check_frame(s, cam, p);
-  if (rc) return rc;
-  if (!out) return fail(RT_ERR_INVALID, "null output");
-  auto t0 = std::chrono::steady_clock::now();
+static int ensure_frame_buffers(Replica *s, size_t npx) {
+  if (npx <= s->cap_px) return RT_OK;
+  (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
+  s->d_color = s->d_radiance = nullptr; s->d_primid = nullptr; s->d_rgb8 = nullptr; s->cap_px = 0;
+  if (hipMalloc((void **)&s->d_color, npx * 24) != hipSuccess || hipMalloc((void **)&s->d_radiance, npx * 24) != hipSuccess ||
+      hipMalloc((void **)&s->d_primid, npx * 4) != hipSuccess || hipMalloc((void **)&s->d_rgb8, npx * 3) != hipSuccess)
+    return fail(RT_ERR_OOM, "output buffers for %zu pixels", npx);
+  s->cap_px = npx;
+  return RT_OK;
+}
+
+// One frame on one device: the whole image, row-major, then to the host.
+static int render_single(Replica *s, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
+  int rc;
   HIP_TRY(hipSetDevice(s->device));
   const size_t npx = (size_t)p->width * p->height;
-  if (npx > s->cap_px) {
-    (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
-    s->d_color = s->d_radiance = nullptr; s->d_primid = nullptr; s->d_rgb8 = nullptr; s->cap_px = 0;
-    if (hipMalloc((void **)&s->d_color, npx * 24) != hipSuccess || hipMalloc((void **)&s->d_radiance, npx * 24) != hipSuccess ||
-        hipMalloc((void **)&s->d_primid, npx * 4) != hipSuccess || hipMalloc((void **)&s->d_rgb8, npx * 3) != hipSuccess)
-      return fail(RT_ERR_OOM, "output buffers for %zu pixels", npx);
-    s->cap_px = npx;
-  }
+  if ((rc = ensure_frame_buffers(s, npx))) return rc;
   hipStream_t stream = nullptr;
   HIP_TRY(hipEventRecord(s->ev0, stream));
-  rc = launch_render(s, cam, p, 0, 1, false, s->d_color, out->radiance ? s->d_radiance : nullptr,
+  rc = launch_render(s, s->ws, cam, p, 0, 1, false, s->d_color, out->radiance ? s->d_radiance : nullptr,
                      out->prim_id ? s->d_primid : nullptr, stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(s->ev1, stream));
@@ -797,13 +967,157 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, rt_output *
   if (out->prim_id) HIP_TRY(hipMemcpy(out->prim_id, s->d_primid, npx * 4, hipMemcpyDeviceToHost));
   if (out->rgb8) HIP_TRY(hipMemcpy(out->rgb8, s->d_rgb8, npx * 3, hipMemcpyDeviceToHost));
   if (stats) {
-    std::memset(stats, 0, sizeof *stats);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     stats->ms_render = ms;
-    stats->paths = (uint64_t)npx * p->samples_per_pixel;
-    if (p->collect_stats && (rc = read_stats(s, stats))) return rc;
-    stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (p->collect_stats && (rc = read_stats(s->ws, stats))) return rc;
+  }
+  return RT_OK;
+}
+
+// One frame on a device group (rt_init_devices): replica i renders the tiles of rank i of world N from its own copy of
+// the scene, on its own stream, driven by its own host thread; its packed tiles go to the group's device 0 as peer
+// copies (one xGMI link per peer, all at once: a gather, not a ring), are un-tiled there and leave for the host in one copy
+// per output.  When only the 8-bit frame is asked for, the replicas quantise first and 3 bytes per pixel cross xGMI
+// instead of 24.  The frame equals the single-device frame bit for bit (RNG keyed on the global pixel).
+static int render_group(rt_scene *sc, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
+  const int N = (int)sc->rep.size();
+  const int W = p->width, H = p->height;
+  const size_t npx = (size_t)W * H;
+  Replica *r0 = sc->rep[0];
+  const bool want_color = out->color != nullptr, want_rad = out->radiance != nullptr, want_id = out->prim_id != nullptr;
+  const bool bytes_only = out->rgb8 && !want_color;          // the 8-bit frame is all of the colour that is wanted
+  int rc;
+  // ---- buffers: packed tiles on each replica's device, their landing place on device 0, the frame on device 0
+  size_t max_slots = 0;
+  std::vector<int> n_tiles(N);
+  for (int i = 0; i < N; ++i) { n_tiles[i] = rt_tile_count(W, H, i, N); max_slots = std::max(max_slots, (size_t)n_tiles[i] * 64); }
+  HIP_TRY(hipSetDevice(r0->device));
+  if ((rc = ensure_frame_buffers(r0, npx))) return rc;
+  for (int i = 0; i < N; ++i) {
+    Replica *r = sc->rep[i];
+    if (max_slots > r->cap_slots) {
+      HIP_TRY(hipSetDevice(r->device));
+      (void)hipFree(r->p_color); (void)hipFree(r->p_radiance); (void)hipFree(r->p_primid); (void)hipFree(r->p_rgb8);
+      if (i > 0) { HIP_TRY(hipSetDevice(r0->device)); (void)hipFree(r->g_color); (void)hipFree(r->g_radiance); (void)hipFree(r->g_primid); (void)hipFree(r->g_rgb8); HIP_TRY(hipSetDevice(r->device)); }
+      r->p_color = r->p_radiance = r->g_color = r->g_radiance = nullptr; r->p_primid = r->g_primid = nullptr; r->p_rgb8 = r->g_rgb8 = nullptr; r->cap_slots = 0;
+      const size_t m = std::max<size_t>(max_slots, 64);
+      if (hipMalloc((void **)&r->p_color, m * 24) != hipSuccess || hipMalloc((void **)&r->p_radiance, m * 24) != hipSuccess ||
+          hipMalloc((void **)&r->p_primid, m * 4) != hipSuccess || hipMalloc((void **)&r->p_rgb8, m * 3) != hipSuccess)
+        return fail(RT_ERR_OOM, "packed tile buffers for %zu slots on device %d", m, r->device);
+      if (i == 0) { r->g_color = r->p_color; r->g_radiance = r->p_radiance; r->g_primid = r->p_primid; r->g_rgb8 = r->p_rgb8; }
+      else {
+        HIP_TRY(hipSetDevice(r0->device));
+        if (hipMalloc((void **)&r->g_color, m * 24) != hipSuccess || hipMalloc((void **)&r->g_radiance, m * 24) != hipSuccess ||
+            hipMalloc((void **)&r->g_primid, m * 4) != hipSuccess || hipMalloc((void **)&r->g_rgb8, m * 3) != hipSuccess)
+          return fail(RT_ERR_OOM, "gather buffers for %zu slots on device %d", m, r0->device);
+      }
+      r->cap_slots = m;
+    }
+    if (!r->stream) { HIP_TRY(hipSetDevice(r->device)); HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); }
+  }
+  // ---- fan out: one host thread per device (replaces the 24 green threads + TQueue of ImageGenerator.hs:37,64-94)
+  std::vector<int> rcs(N, RT_OK);
+  std::vector<std::string> errs(N);
+  auto work = [&](int i) {
+    Replica *r = sc->rep[i];
+    auto body = [&]() -> int {
+      HIP_TRY(hipSetDevice(r->device));
+      if (n_tiles[i] == 0) return RT_OK;
+      const size_t slots = (size_t)n_tiles[i] * 64;
+      HIP_TRY(hipEventRecord(r->ev0, r->stream));
+      int rc2 = launch_render(r, r->ws, cam, p, i, N, true, r->p_color, want_rad ? r->p_radiance : nullptr, want_id ? r->p_primid : nullptr, r->stream);
+      if (rc2) return rc2;
+      HIP_TRY(hipEventRecord(r->ev1, r->stream));
+      if (bytes_only) {
+        const long long n = (long long)slots * 3;
+        hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r->stream, r->p_color, r->p_rgb8, n);
+        HIP_TRY(hipGetLastError());
+      }
+      if (i > 0) {                                           // the exchange step: packed tiles to device 0
+        if (bytes_only) HIP_TRY(hipMemcpyPeerAsync(r->g_rgb8, r0->device, r->p_rgb8, r->device, slots * 3, r->stream));
+        else if (want_color || out->rgb8) HIP_TRY(hipMemcpyPeerAsync(r->g_color, r0->device, r->p_color, r->device, slots * 24, r->stream));
+        if (want_rad) HIP_TRY(hipMemcpyPeerAsync(r->g_radiance, r0->device, r->p_radiance, r->device, slots * 24, r->stream));
+        if (want_id) HIP_TRY(hipMemcpyPeerAsync(r->g_primid, r0->device, r->p_primid, r->device, slots * 4, r->stream));
+      }
+      HIP_TRY(hipStreamSynchronize(r->stream));
+      return RT_OK;
+    };
+    rcs[i] = body();
+    if (rcs[i]) errs[i] = g_err;                             // g_err is thread-local: hand the text to the calling thread
+  };
+  {
+    std::vector<std::thread> th;
+    for (int i = 1; i < N; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto &t : th) t.join();
+  }
+  for (int i = 0; i < N; ++i) if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
+  // ---- assemble on device 0
+  HIP_TRY(hipSetDevice(r0->device));
+  hipStream_t st0 = r0->stream;
+  for (int i = 0; i < N; ++i) {
+    Replica *r = sc->rep[i];
+    if (n_tiles[i] == 0) continue;
+    if (bytes_only) { if ((rc = untile_launch(W, H, i, N, r->g_rgb8, r0->d_rgb8, 3, true, st0))) return rc; }
+    else if (want_color || out->rgb8) { if ((rc = untile_launch(W, H, i, N, r->g_color, r0->d_color, 3, false, st0))) return rc; }
+    if (want_rad && (rc = untile_launch(W, H, i, N, r->g_radiance, r0->d_radiance, 3, false, st0))) return rc;
+    if (want_id) {
+      static_assert(sizeof(int32_t) == 4, "prim ids travel as 4-byte slots");
+      if ((rc = untile_launch(W, H, i, N, r->g_primid, r0->d_primid, 4, true, st0))) return rc;
+    }
+  }
+  if (out->rgb8 && !bytes_only) {
+    const long long n = (long long)npx * 3;
+    hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st0, r0->d_color, r0->d_rgb8, n);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(st0));
+  if (out->color) HIP_TRY(hipMemcpy(out->color, r0->d_color, npx * 24, hipMemcpyDeviceToHost));
+  if (out->radiance) HIP_TRY(hipMemcpy(out->radiance, r0->d_radiance, npx * 24, hipMemcpyDeviceToHost));
+  if (out->prim_id) HIP_TRY(hipMemcpy(out->prim_id, r0->d_primid, npx * 4, hipMemcpyDeviceToHost));
+  if (out->rgb8) HIP_TRY(hipMemcpy(out->rgb8, r0->d_rgb8, npx * 3, hipMemcpyDeviceToHost));
+  if (stats) {
+    for (int i = 0; i < N; ++i) {
+      Replica *r = sc->rep[i];
+      if (n_tiles[i] == 0) continue;
+      HIP_TRY(hipSetDevice(r->device));
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, r->ev0, r->ev1));
+      stats->ms_render = std::max(stats->ms_render, (double)ms);   // the slowest device sets the frame
+      if (p->collect_stats && (rc = read_stats(r->ws, stats))) return rc;
+    }
+    HIP_TRY(hipSetDevice(r0->device));
+  }
+  return RT_OK;
+}
+
+extern "C" {
+
+int rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
+  int rc = check_frame(s, cam, p);
+  if (rc) return rc;
+  if (!out) return fail(RT_ERR_INVALID, "null output");
+  auto t0 = std::chrono::steady_clock::now();
+  if (stats) { std::memset(stats, 0, sizeof *stats); stats->paths = (uint64_t)p->width * p->height * p->samples_per_pixel; }
+  rc = s->rep.size() == 1 ? render_single(s->rep[0], cam, p, out, stats) : render_group(s, cam, p, out, stats);
+  if (rc) return rc;
+  if (stats) stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return RT_OK;
+}
+
+static int render_tiles_common(rt_scene *sc, Workspace &ws, const rt_camera *cam, const rt_params *p, int32_t rank, int32_t world,
+                               void *d_color, void *d_radiance, void *d_prim_id, void *stream, rt_stats *stats) {
+  Replica *s = sc->rep[0];
+  int rc = launch_render(s, ws, cam, p, rank, world, true, (double *)d_color, (double *)d_radiance, (int32_t *)d_prim_id, (hipStream_t)stream);
+  if (rc) return rc;
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->paths = (uint64_t)rt_tile_count(p->width, p->height, rank, world) * 64 * p->samples_per_pixel;
+    if (p->collect_stats) {
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      if ((rc = read_stats(ws, stats))) return rc;
+    }
   }
   return RT_OK;
 }
@@ -814,32 +1128,30 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p
   if (rc) return rc;
   if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad rank/world");
   if (!d_color && !d_radiance && !d_prim_id) return fail(RT_ERR_INVALID, "no output buffer");
-  HIP_TRY(hipSetDevice(s->device));
-  rc = launch_render(s, cam, p, rank, world, true, (double *)d_color, (double *)d_radiance, (int32_t *)d_prim_id, (hipStream_t)stream);
-  if (rc) return rc;
-  if (stats) {
-    std::memset(stats, 0, sizeof *stats);
-    stats->paths = (uint64_t)s->tl_n * 64 * p->samples_per_pixel;
-    if (p->collect_stats) {
-      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-      if ((rc = read_stats(s, stats))) return rc;
-    }
-  }
-  return RT_OK;
+  HIP_TRY(hipSetDevice(s->rep[0]->device));
+  return render_tiles_common(s, s->rep[0]->ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, stream, stats);
 }
 
-int rt_kernel_times(rt_scene *s, double *sum_ms, int32_t *n_launches) {
-  if (!s || !sum_ms || !n_launches) return fail(RT_ERR_INVALID, "null argument");
-  HIP_TRY(hipSetDevice(s->device));
-  double sum = 0;
-  for (int i = 0; i < s->kt_pending; ++i) {
-    float ms = 0;
-    HIP_TRY(hipEventSynchronize(s->kt_events[2 * i + 1]));
-    HIP_TRY(hipEventElapsedTime(&ms, s->kt_events[2 * i], s->kt_events[2 * i + 1]));
-    sum += ms;
+int rt_kernel_times(rt_scene *sc, double *sum_ms, int32_t *n_launches) {
+  if (!sc || sc->rep.empty() || !sum_ms || !n_launches) return fail(RT_ERR_INVALID, "null argument");
+  double worst = 0;
+  int n0 = 0;
+  for (size_t k = 0; k < sc->rep.size(); ++k) {
+    Replica *s = sc->rep[k];
+    HIP_TRY(hipSetDevice(s->device));
+    double sum = 0;
+    for (int i = 0; i < s->kt_pending; ++i) {
+      float ms = 0;
+      HIP_TRY(hipEventSynchronize(s->kt_events[2 * i + 1]));
+      HIP_TRY(hipEventElapsedTime(&ms, s->kt_events[2 * i], s->kt_events[2 * i + 1]));
+      sum += ms;
+    }
+    if (k == 0) n0 = s->kt_pending;
+    worst = std::max(worst, sum);
+    s->kt_pending = 0;
   }
-  *sum_ms = sum; *n_launches = s->kt_pending;
-  s->kt_pending = 0;
+  HIP_TRY(hipSetDevice(sc->rep[0]->device));
+  *sum_ms = worst; *n_launches = n0;
   return RT_OK;
 }
 
@@ -848,15 +1160,7 @@ int rt_untile_device(int32_t W, int32_t H, int32_t rank, int32_t world, const vo
   int rc = ensure_init();
   if (rc) return rc;
   if (!d_packed || !d_image || n_comp <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
-  int n = 0;
-  const int32_t *d_t = nullptr;
-  if ((rc = cached_tiles(W, H, rank, world, &d_t, &n))) return rc;
-  if (n == 0) return RT_OK;
-  const size_t slots = (size_t)n * 64;
-  hipLaunchKernelGGL(k_untile, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     d_t, n, tiles_x_of(W), W, H, n_comp, (const double *)d_packed, (double *)d_image);
-  HIP_TRY(hipGetLastError());
-  return RT_OK;
+  return untile_launch(W, H, rank, world, d_packed, d_image, n_comp, false, (hipStream_t)stream);
 }
 
 int rt_untile_bytes_device(int32_t W, int32_t H, int32_t rank, int32_t world, const void *d_packed, void *d_image,
@@ -864,15 +1168,7 @@ int rt_untile_bytes_device(int32_t W, int32_t H, int32_t rank, int32_t world, co
   int rc = ensure_init();
   if (rc) return rc;
   if (!d_packed || !d_image || n_bytes <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
-  int n = 0;
-  const int32_t *d_t = nullptr;
-  if ((rc = cached_tiles(W, H, rank, world, &d_t, &n))) return rc;
-  if (n == 0) return RT_OK;
-  const size_t slots = (size_t)n * 64;
-  hipLaunchKernelGGL(k_untile_bytes, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     d_t, n, tiles_x_of(W), W, H, n_bytes, (const uint8_t *)d_packed, (uint8_t *)d_image);
-  HIP_TRY(hipGetLastError());
-  return RT_OK;
+  return untile_launch(W, H, rank, world, d_packed, d_image, n_bytes, true, (hipStream_t)stream);
 }
 
 int rt_quantize_device(const void *d_color, void *d_rgb8, int64_t n_values, void *stream) {
