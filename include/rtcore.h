@@ -225,6 +225,21 @@ int  rt_render_tiles_device(rt_scene *scene, const rt_camera *cam, const rt_para
                             void *d_color, void *d_radiance, void *d_prim_id,
                             void *stream, rt_stats *stats);
 
+/* rt_render_tiles_device for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results to the bit; but the launch
+ * workspace (chunk counter, statistics, tile list, path records, per-path radiance) is a 128-MiB static device array
+ * inside the library instead of buffers that grow on demand, and the call makes no hipMalloc / hipFree / event creation.
+ * Limits: at most 262,144 tiles per rank (16.7 Mpixel shares); 64 * samples_per_pixel * 24 bytes (one tile's samples) must
+ * fit 64 MiB (spp <= 43,690) - a frame whose samples exceed 64 MiB is rendered in several launches, which costs time, not
+ * correctness; one workgroup's path records must fit 62 MiB (always true for BVH depth <= 60).  Beyond them:
+ * RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race (the same holds
+ * for two rt_render_tiles_device calls in flight on ONE rt_scene - at most one render in flight per scene, and successive
+ * calls on a scene must be stream-ordered).  rt_kernel_times does not see these launches (creating an event allocates). */
+int  rt_render_tiles_device_noalloc(rt_scene *scene, const rt_camera *cam, const rt_params *params,
+                                    int32_t rank, int32_t world,
+                                    void *d_color, void *d_radiance, void *d_prim_id,
+                                    void *stream, rt_stats *stats);
+
 /* Measurement hook (no counterpart in the reference): sum of the durations, in ms, of the k_render_tiles launches
  * recorded on this scene since the previous call, taken with HIP events on the stream each launch went to, and
  * their number (at most 256 are kept).  Blocks until those launches have finished.  bench.py's roofline uses it.

@@ -47,11 +47,32 @@ constexpr int RT_MAX_DEVICES = 64;
 struct DevCtx {
   bool ready = false;
   int n_cu = 0;
+  unsigned char *scratch = nullptr;     // this device's copy of the static scratch array below (hipGetSymbolAddress)
 };
 DevCtx g_dev[RT_MAX_DEVICES];
 std::mutex g_init_mu;
 // The devices one rt_render call fans out over (rt_init_devices); entries may repeat ("virtual devices": tests on one GPU).
 std::vector<int> g_group;
+
+}  // namespace
+
+// ---- scratch of the entry point that allocates nothing (rt_render_tiles_device_noalloc) -------------------------------
+// A file-scope device array: every GPU the library runs on holds its own copy, at its own address, until the process
+// ends.  In host code the NAME `scratch` is only a handle for hipGetSymbolAddress - never a device address; the address
+// is resolved once per device in init_device() and kept in g_dev[device].scratch, and that pointer is what kernels,
+// hipMemsetAsync and copies receive.  Layout (all offsets multiples of 256):
+//   [0, 4 KiB)            chunk counter (4 B) at 0, STAT_COUNT counters at 256
+//   [4 KiB, +1 MiB)       this rank's tile list: at most RT_SCRATCH_MAX_TILES entries
+//   [.., 64 MiB)          path records (cold rows + stack overflow rows): as many resident waves as fit
+//   [64 MiB, 128 MiB)     per-path radiance of one launch: the frame is rendered in as many launches as that takes
+#define RT_SCRATCH_BYTES ((size_t)128 << 20)
+#define RT_SCRATCH_TILES_OFF ((size_t)4096)
+#define RT_SCRATCH_MAX_TILES ((size_t)262144)
+#define RT_SCRATCH_REC_OFF (RT_SCRATCH_TILES_OFF + RT_SCRATCH_MAX_TILES * 4)
+#define RT_SCRATCH_SAMPLES_OFF ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char scratch[RT_SCRATCH_BYTES];
+
+namespace {
 
 int init_device(int device) {            // with `device` current; idempotent
   std::lock_guard<std::mutex> g(g_init_mu);
@@ -60,6 +81,10 @@ int init_device(int device) {            // with `device` current; idempotent
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c.n_cu = prop.multiProcessorCount;
+  void *p = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));     // this device's copy of the array
+  if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+  c.scratch = (unsigned char *)p;
   c.ready = true;
   return RT_OK;
 }
@@ -1130,6 +1155,34 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p
   if (!d_color && !d_radiance && !d_prim_id) return fail(RT_ERR_INVALID, "no output buffer");
   HIP_TRY(hipSetDevice(s->rep[0]->device));
   return render_tiles_common(s, s->rep[0]->ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, stream, stats);
+}
+
+// The same frame share with NO allocation anywhere on the way: the launch workspace is the static device array
+// `scratch` (through the per-device address resolved in init_device), the tile list is written by a kernel, no HIP
+// event is created.  A frame larger than the sample area takes several launches; what does not fit at all is refused.
+int rt_render_tiles_device_noalloc(rt_scene *s, const rt_camera *cam, const rt_params *p, int32_t rank, int32_t world,
+                                   void *d_color, void *d_radiance, void *d_prim_id, void *stream, rt_stats *stats) {
+  int rc = check_frame(s, cam, p);
+  if (rc) return rc;
+  if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad rank/world");
+  if (!d_color && !d_radiance && !d_prim_id) return fail(RT_ERR_INVALID, "no output buffer");
+  Replica *r = s->rep[0];
+  HIP_TRY(hipSetDevice(r->device));
+  unsigned char *base = g_dev[r->device].scratch;            // the device address of `scratch` on THIS GPU (never the symbol itself)
+  if (!g_dev[r->device].ready || !base) return fail(RT_ERR_HIP, "static scratch of device %d was not resolved by rt_init", r->device);
+  Workspace ws;
+  ws.fixed = true;
+  ws.counter = (uint32_t *)base;
+  ws.stats = (unsigned long long *)(base + 256);
+  ws.tiles = (int32_t *)(base + RT_SCRATCH_TILES_OFF); ws.tiles_cap = RT_SCRATCH_MAX_TILES;
+  ws.fscratch = (double *)(base + RT_SCRATCH_REC_OFF); ws.fscratch_cap = RT_SCRATCH_SAMPLES_OFF - RT_SCRATCH_REC_OFF;
+  ws.samples = (double *)(base + RT_SCRATCH_SAMPLES_OFF); ws.samples_cap = RT_SCRATCH_BYTES - RT_SCRATCH_SAMPLES_OFF;
+  static_assert(256 + STAT_COUNT * sizeof(unsigned long long) <= RT_SCRATCH_TILES_OFF, "counters overlap the tile list");
+  static_assert(RT_SCRATCH_REC_OFF % 256 == 0 && RT_SCRATCH_REC_OFF < RT_SCRATCH_SAMPLES_OFF, "scratch layout");
+  // every call shares this GPU's array and finds the previous call's contents in it: the counter is cleared per launch
+  // (launch_kernel), the statistics when they are collected, the tile list is rewritten, records and samples are
+  // written before they are read
+  return render_tiles_common(s, ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, stream, stats);
 }
 
 int rt_kernel_times(rt_scene *sc, double *sum_ms, int32_t *n_launches) {
