@@ -26,6 +26,15 @@ NODE_BYTES = 64      # DNode<float>: both child boxes (FP32, conservative) + 2 r
 PRIM_BYTES = 80      # DPrim: 9 doubles + material + kind
 MAT_BYTES = 64       # DMaterial fetched per shaded hit
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+# Vector (non-MFMA) peaks of MI355X, MI355X_MICROARCH.md / SURVEY section 7: 157.3 TFLOP/s FP32 (packed), 78.6 TFLOP/s FP64
+VALU_PEAK_TFLOPS_F32 = 157.3
+VALU_PEAK_TFLOPS_F64 = 78.6
+# SURVEY 8(d)'s flop weights of the algorithm: 25 per box test (2 per visited node; FP32 here), 30 + 15 + 6 per triangle
+# test that runs to t (the kernel's predicated test always does; FP64), 25 per sphere test, ~60 per shaded hit + 33 for the
+# accepted hit's normal / face / point, ~40 per sky lookup (one per path when a sky texture is set)
+FLOPS_NODE, FLOPS_TRI, FLOPS_SPHERE, FLOPS_PLANE, FLOPS_SHADED, FLOPS_SKY = 50, 51, 25, 20, 93, 40
+# scenes up to this size live in L2 (8 x 4 MB) / Infinity Cache (256 MB): their roofline is the VALU one
+CACHE_RESIDENT_BYTES = 64 << 20
 
 
 def main():
@@ -36,7 +45,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=100)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c3", "c2", "c5"])
+    ap.add_argument("--workload", default="c4", choices=["c4", "c4v", "c3", "c2", "c5"],
+                    help="c4: the metric config as shipped in obli.json (bvhMaxDepth 10, HDR sky); c4v: round 1's variant (bvhMaxDepth 32, solid background)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
@@ -59,7 +69,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    mk = {"c4": scenes.c4_blob63k, "c3": scenes.c3_blob988, "c2": scenes.c2_spheres, "c5": scenes.c5_multi}[args.workload]
+    mk = {"c4": scenes.c4_shipped, "c4v": scenes.c4_blob63k, "c3": scenes.c3_blob988, "c2": scenes.c2_spheres, "c5": scenes.c5_multi}[args.workload]
     spec = mk(width=args.width, height=args.height, spp=args.spp)
     W, H = spec.width, spec.height
     t0 = time.time()
@@ -148,48 +158,74 @@ def main():
         if n <= 0:
             raise SystemExit("rth_format_ppm failed")
     if rank == 0:
-        achieved = my_alg_bytes / (kernel_ms * 1e-3) / 1e9        # rank 0's kernel: algorithmic GB/s
+        my_rays = max(1, mine[0] + mine[1])
+        alg_gbs = my_alg_bytes / (kernel_ms * 1e-3) / 1e9         # rank 0's kernel: algorithmic bytes per second
+        sky_lookups = mine[7] if spec.sky is not None else 0      # every path ends in one background lookup (Trace.hs:22,25)
+        flops32 = FLOPS_NODE * mine[2]
+        flops64 = FLOPS_TRI * mine[3] + FLOPS_SPHERE * mine[4] + FLOPS_PLANE * mine[5] + FLOPS_SHADED * mine[6] + FLOPS_SKY * sky_lookups
+        alg_tflops = (flops32 + flops64) / (kernel_ms * 1e-3) / 1e12
         traffic, pmc = None, {}
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured HBM bytes per launch (rocprofv3 --pmc), if committed
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf)).get(f"{args.workload}_{W}x{H}_spp{spec.spp}_n{world}")
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
-                pmc = {k: rec[k] for k in ("valu_busy_frac", "valu_lane_utilisation", "l2_hit_rate") if rec and k in rec}
+                pmc = {k: rec[k] for k in ("valu_busy_frac", "valu_lane_utilisation", "l2_hit_rate", "source") if rec and k in rec}
             except Exception:
                 traffic = None
+        scene_bytes = NODE_BYTES * (scene.bvh.n_nodes - scene.bvh.n_leaves) + PRIM_BYTES * scene.bvh.n_prims
+        if spec.sky is not None:
+            scene_bytes += spec.sky[1].nbytes
+        common = {"traffic": traffic, "kernel": "k_render_tiles<float,false,true>", "kernel_ms": round(kernel_ms, 3), "launches": k_n,
+                  "render_plus_resolve_ms": round(render_ms, 3),
+                  "nodes_per_ray": round(mine[2] / my_rays, 2), "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / my_rays, 2),
+                  "reference_algorithm": {
+                      "note": "the same rays through the reference's median-split tree (box_precision=1): SURVEY 8(d)'s figure",
+                      "nodes_per_ray": round(ref_work[0] / max(1, ref_work[3]), 2),
+                      "prim_tests_per_ray": round(ref_work[1] / max(1, ref_work[3]), 2),
+                      "bytes_per_ray": round((NODE_BYTES * ref_work[0] + PRIM_BYTES * ref_work[1] + MAT_BYTES * ref_work[2]) / max(1, ref_work[3]), 1)},
+                  "pmc": pmc, "scene_bytes": scene_bytes}
+        if scene_bytes <= CACHE_RESIDENT_BYTES:
+            # cache-resident scene: the memory side is not the bound (measured HBM-side traffic is a few % of the algorithmic
+            # bytes), the vector ALUs are (SURVEY 8d names VALU as the co-limit).  achieved = the ALGORITHM's flops per launch
+            # (8d's weights x the device counters of the traversal that ran) / kernel time, against the FP32 vector peak.
+            roofline = {"bound": "valu", "achieved": round(alg_tflops, 3), "peak": VALU_PEAK_TFLOPS_F32, "unit": "TFLOP/s",
+                        "frac": round(alg_tflops / VALU_PEAK_TFLOPS_F32, 5),
+                        "algorithmic_flops_per_launch": flops32 + flops64, "fp64_share_of_flops": round(flops64 / max(1, flops32 + flops64), 3),
+                        "frac_with_fp64_part_rated_at_78.6": round((flops32 / VALU_PEAK_TFLOPS_F32 + flops64 / VALU_PEAK_TFLOPS_F64) / (kernel_ms * 1e-3) / 1e12, 5),
+                        "flops_per_ray": round((flops32 + flops64) / my_rays, 1),
+                        "on_chip_bytes": {"algorithmic_bytes_per_launch": my_alg_bytes, "bytes_per_ray": round(my_alg_bytes / my_rays, 1),
+                                          "rate_GBs": round(alg_gbs, 1), "served_by": "LDS (top BVH levels), L1, L2; not an HBM figure"},
+                        "hbm_frac_measured": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "frac = useful algorithmic flops / vector peak: low because most issued VALU work is not arithmetic of the "
+                                "algorithm (selects, votes, address and stack handling, Philox) and lanes idle between states; the SIMDs "
+                                "themselves are issue-saturated (pmc.valu_busy_frac). See DESIGN.md section 7"}
+        else:
+            # the scene exceeds the caches: HBM is the memory-side bound.  achieved = MEASURED HBM bytes per launch (PMC) / kernel
+            # time when a counter record is committed for this workload, else the algorithmic bytes (then an upper bound).
+            hb = traffic if traffic is not None else my_alg_bytes
+            gbs = hb / (kernel_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                        "achieved_is": "measured HBM traffic (FETCH_SIZE x2 + WRITE_SIZE)" if traffic is not None else "algorithmic bytes (no counter record)",
+                        "algorithmic_bytes_per_launch": my_alg_bytes, "bytes_per_ray": round(my_alg_bytes / my_rays, 1),
+                        "valu": {"achieved_TFLOPs": round(alg_tflops, 3), "frac_of_157.3": round(alg_tflops / VALU_PEAK_TFLOPS_F32, 5)}}
+        roofline.update(common)
+        lights = f"{len(spec.lights)} point light" + ("" if len(spec.lights) == 1 else "s")
+        sky_txt = (f"synthetic HDR sky {spec.sky[1].shape[1]}x{spec.sky[1].shape[0]} RGBF (the author's .hdr is not in the reference)"
+                   if spec.sky is not None else f"no sky texture, background {spec.background['tag']}")
         out = {
             "metric": "Mrays/s + frame time, 63k-tri monkey 1080p AA-100, at 1/2/4/8 MI355X",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{spec.name}: {spec.n_triangles()} triangles, {W}x{H}, {spec.spp} spp, maxBounces {spec.max_bounces}, "
-                                   f"leafThreshold {spec.leaf_threshold}, bvhMaxDepth {spec.bvh_max_depth}, 1 point light",
+                                   f"leafThreshold {spec.leaf_threshold}, bvhMaxDepth {spec.bvh_max_depth}, {lights}, {sky_txt}",
                        "parallelism": f"tiles{world}", "rays_per_frame": rays_total, "rays_shadow_culled": tot[8], "reference_rays_per_frame": rays_total + tot[8],
                        "paths_per_frame": tot[7],
                        "frame_time_s": round(ms_per_step * 1e-3, 5), "kernel_ms": round(kernel_ms_max, 3),
                        "setup_s": round(t_setup, 3), "d2h_plus_ppm_text_s": round(t_ppm, 3),
                        "end_to_end_s": round(t_setup + ms_per_step * 1e-3 + t_ppm, 3)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_render_tiles<float,false,true>", "kernel_ms": round(kernel_ms, 3), "launches": k_n,
-                         "render_plus_resolve_ms": round(render_ms, 3),
-                         "algorithmic_bytes_per_launch": my_alg_bytes,
-                         "bytes_per_ray": round(my_alg_bytes / max(1, mine[0] + mine[1]), 1),
-                         "nodes_per_ray": round(mine[2] / max(1, mine[0] + mine[1]), 2),
-                         "prim_tests_per_ray": round((mine[3] + mine[4] + mine[5]) / max(1, mine[0] + mine[1]), 2),
-                         "reference_algorithm": {
-                             "note": "the same rays through the reference's median-split tree (box_precision=1): SURVEY 8(d)'s figure",
-                             "nodes_per_ray": round(ref_work[0] / max(1, ref_work[3]), 2),
-                             "prim_tests_per_ray": round(ref_work[1] / max(1, ref_work[3]), 2),
-                             "bytes_per_ray": round((NODE_BYTES * ref_work[0] + PRIM_BYTES * ref_work[1] + MAT_BYTES * ref_work[2]) / max(1, ref_work[3]), 1)},
-                         "pmc": pmc,
-                         "scene_bytes": NODE_BYTES * (scene.bvh.n_nodes - scene.bvh.n_leaves) + PRIM_BYTES * scene.bvh.n_prims,
-                         "note": "algorithmic bytes = what the kernel's own traversal fetches (64 B per node visit, 80 B per primitive "
-                                 "test, 64 B per shaded hit); they are mostly served on chip (LDS / L1 / L2, Infinity Cache) when the "
-                                 "scene fits the caches, so frac is not an HBM utilisation; `traffic` is the measured HBM-side volume "
-                                 "per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, committed under profiles/). The kernel is VALU-issue "
-                                 "bound, see DESIGN.md section 7"},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_threads)

@@ -170,6 +170,10 @@ typedef struct rt_stats {
                                   because the surface faces away from the light: their term is max(0, n.l) = 0 either way */
   uint64_t rays_literal;       /* queries answered by the literal walk of the reference's tree: a plane was crossed beyond its leaf
                                   box's exit, where the reference's answer depends on its traversal history (BVH.hs:137-138) */
+  /* census of the SHADE body's sub-blocks (hit, light term, shadow set-up, scatter, finish): lanes that ran each, and
+   * wave-level trips in which at least one lane did; cyc_shade_detail: their time in experiment builds (-DRT_TIMERS):
+   * loads, hit, light, set-up, scatter, finish, begin-query */
+  uint64_t shade_lanes[5], shade_trips[5], cyc_shade_detail[7];
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

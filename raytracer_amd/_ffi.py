@@ -67,7 +67,8 @@ class rt_stats(C.Structure):
                 ("sched_node_steps", C.c_uint64), ("sched_prim_steps", C.c_uint64), ("sched_shade_steps", C.c_uint64),
                 ("top_node_hits", C.c_uint64), ("sched_live_lanes", C.c_uint64),
                 ("cyc_vote", C.c_uint64), ("cyc_node", C.c_uint64), ("cyc_prim", C.c_uint64), ("cyc_shade", C.c_uint64), ("cyc_refill", C.c_uint64),
-                ("rays_shadow_culled", C.c_uint64), ("rays_literal", C.c_uint64)]
+                ("rays_shadow_culled", C.c_uint64), ("rays_literal", C.c_uint64),
+                ("shade_lanes", C.c_uint64 * 5), ("shade_trips", C.c_uint64 * 5), ("cyc_shade_detail", C.c_uint64 * 7)]
 
 
 class rth_config_view(C.Structure):

@@ -29,6 +29,8 @@ struct KScene {
   const double *plane_boxes;   // 6 doubles per plane: the FP64 box of the leaf holding it
   const double *tri_normals;   // 6 doubles per primitive (triangles only): n = normalize(e1 x e2) (Triangle.hs:51) and normalize(n) (Light.hs:19)
   const void *sky;
+  const double *sky_u_tab;     // (cos phi_k, sin phi_k), phi_k = 2 pi (k / w - 0.5), k = -2 .. w + 2: the texel columns' boundary directions
+  const double *sky_v_tab;     // cos(pi k / h), k = -2 .. h + 2 (+inf below 0, -inf above h): the texel rows' thresholds on y
   int32_t root_ref;
   int32_t ref_root_ref;        // root of the reference's tree (== root_ref unless FAST)
   int32_t n_lights;
@@ -62,7 +64,12 @@ struct KFrame {
   unsigned long long *dbg;     // experiment builds (-DRT_TIMERS) only: 4 words per wave, see the end of k_render_tiles
 };
 
-enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_SHADOW_CULLED, STAT_LITERAL, STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL, STAT_COUNT };
+enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PLANE, STAT_SHADED, STAT_IT_NODE, STAT_IT_PRIM, STAT_IT_SHADE, STAT_LIVE, STAT_TOPHIT, STAT_SHADOW_CULLED, STAT_LITERAL,
+       STAT_SH_L0, STAT_SH_L1, STAT_SH_L2, STAT_SH_L3, STAT_SH_L4,   // lanes that ran SHADE's sub-blocks: hit, light term, shadow set-up, scatter, finish
+       STAT_SH_W0, STAT_SH_W1, STAT_SH_W2, STAT_SH_W3, STAT_SH_W4,   // SHADE trips in which at least one lane ran them
+       STAT_T_VOTE, STAT_T_NODE, STAT_T_PRIM, STAT_T_SHADE, STAT_T_REFILL,
+       STAT_T_SH0, STAT_T_SH1, STAT_T_SH2, STAT_T_SH3, STAT_T_SH4, STAT_T_SH5, STAT_T_SH6,   // -DRT_TIMERS: SHADE's time by sub-block (loads, hit, light, set-up, scatter, finish, begin query)
+       STAT_COUNT };
 
 // cold code (once per path, not per traversal step).  Inlined: taking KScene/KFrame by reference out of line cost more
 // scratch than it saved registers; only the libm-heavy leaves (sky_uv, pow_gamma) are real calls.
@@ -108,15 +115,63 @@ __device__ __attribute__((noinline)) double2 sky_uv(double nx, double ny, double
   return r;
 }
 
+// Texel of a unit direction (SkySphere.hs:35-41): i = clamp(floor(u w)), j = clamp(floor(v h)) with u = 0.5 + atan2(z, x) / 2pi,
+// v = 0.5 - asin(y) / pi.  Only the INTEGERS matter, so the two FP64 libm calls (~400 VALU instructions, once per path) are
+// replaced by their inverse on the host: floor(v h) >= k  <=>  y <= cos(pi k / h), and floor(u w) >= k  <=>  the direction
+// (x, z) lies counter-clockwise of the boundary direction (cos phi_k, sin phi_k), phi_k = 2pi (k / w - 0.5), i.e.
+// cos phi_k * z - sin phi_k * x >= 0 - valid while the two are less than pi apart.  A cheap FP32 estimate gives the texel
+// to within one; four exact FP64 threshold tests around it (tables sky_v_tab / sky_u_tab, built at upload) give the texel.
+// A direction within ~1e-16 of a texel boundary may fall on the other side than libm's rounding puts it - the same class of
+// difference as between two libm implementations (ocml here, glibc under GHC).  If the estimate is ever off by more than
+// one texel (or NaN), the bracketing tests fail and the lane takes the libm path (sky_uv).
+#define SKY_TAB_PAD 2      // the tables start at k = -SKY_TAB_PAD
+RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
+  const int w = sc.sky_w, h = sc.sky_h;
+  const double dy = fmax(-1.0, fmin(1.0, n.y));
+  bool ok = true;
+  {                                                                 // ---- column: FP32 estimate of atan2(z, x)
+    const float x = (float)n.x, z = (float)n.z, ax = fabsf(x), az = fabsf(z);
+    const float mx = fmaxf(ax, az), mn = fminf(ax, az);
+    const float a = mn * __frcp_rn(mx), q = a * a;
+    float r = a * (0.99997726f + q * (-0.33262347f + q * (0.19354346f + q * (-0.11643287f + q * (0.05265332f + q * -0.01172120f)))));
+    r = az > ax ? 1.57079637f - r : r;
+    r = x < 0.0f ? 3.14159274f - r : r;
+    r = z < 0.0f ? -r : r;
+    int i0 = (int)floorf((0.5f + r * 0.159154943f) * (float)w);
+    i0 = i0 < 0 ? 0 : (i0 > w - 1 ? w - 1 : i0);
+    const double2 *t = (const double2 *)sc.sky_u_tab + (i0 - 1 + SKY_TAB_PAD);          // boundaries i0-1 .. i0+2
+    const double2 b0 = t[0], b1 = t[1], b2 = t[2], b3 = t[3];
+    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c1 = b1.x * n.z - b1.y * n.x >= 0.0;
+    const bool c2 = b2.x * n.z - b2.y * n.x >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
+    ok = ok && c0 && !c3 && n.z != 0.0 && (mx == mx) && mx > 0.0f;   // z = +-0: atan2 tells +pi from -pi by the sign of zero, a cross product cannot
+    i = (long long)i0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
+  }
+  {                                                                 // ---- row: FP32 estimate of asin(y) (Abramowitz-Stegun 4.4.45)
+    const float y = (float)dy, ay = fabsf(y);
+    float p = sqrtf(fmaxf(0.0f, 1.0f - ay)) * (1.5707288f + ay * (-0.2121144f + ay * (0.0742610f + ay * -0.0187293f)));
+    p = 1.57079637f - p;
+    p = y < 0.0f ? -p : p;
+    int j0 = (int)floorf((0.5f - p * 0.318309886f) * (float)h);
+    j0 = j0 < 0 ? 0 : (j0 > h - 1 ? h - 1 : j0);
+    const double *t = sc.sky_v_tab + (j0 - 1 + SKY_TAB_PAD);                            // thresholds j0-1 .. j0+2
+    const bool c0 = dy <= t[0], c1 = dy <= t[1], c2 = dy <= t[2], c3 = dy <= t[3];
+    ok = ok && c0 && (!c3 || j0 + 2 > h);                           // (dy = -1 reaches the last threshold: clamped below)
+    j = (long long)j0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
+  }
+  if (!ok) {                                                        // never on a valid estimate; keeps the result defined
+    const double2 uv = sky_uv(n.x, n.y, n.z);
+    i = (long long)floor(uv.x * (double)w); j = (long long)floor(uv.y * (double)h);
+  }
+  i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+  j = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+}
+
 // ---------------------------------------------------------------- background (Trace.hs:78-83)
 RT_COLD d3 background(const KScene &sc, d3 dir) {
   if (sc.sky_format != RT_SKY_NONE) {                               // SkySphere.hs:32-47
     d3 n = normalize3(dir);
-    const double2 uv = sky_uv(n.x, n.y, n.z);
-    const double u = uv.x, v = uv.y;
-    long long i = (long long)floor(u * (double)sc.sky_w), j = (long long)floor(v * (double)sc.sky_h);
-    i = i < 0 ? 0 : (i > sc.sky_w - 1 ? sc.sky_w - 1 : i);
-    j = j < 0 ? 0 : (j > sc.sky_h - 1 ? sc.sky_h - 1 : j);
+    long long i, j;
+    sky_texel(sc, n, i, j);
     size_t k = ((size_t)j * sc.sky_w + (size_t)i) * 3;
     if (sc.sky_format == RT_SKY_RGB8) {
       const uint8_t *p = (const uint8_t *)sc.sky;

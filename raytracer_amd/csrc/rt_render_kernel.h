@@ -29,13 +29,17 @@
 // The per-lane traversal stack (ref, entry distance) is in LDS, [wave][entry][lane].
 //
 // State of a lane, in ONE register: cur >= 0 internal node index, CUR_IDLE no item, CUR_DONE query finished (waits
-// for SHADE), CUR_POP owes a pop, anything else negative = leaf reference ~first_primitive.
+// for SHADE), CUR_POP owes a pop, CUR_FIN / CUR_FIN0 path ended (waits for the refill step, which writes its sample and
+// hands the lane a new item), anything else negative = leaf reference ~first_primitive.
 // Numerics: emission and each light's term are added to `a` as they arrive, i.e. the reference's
 // `e + surf*(l1 + (l2 + ...)) + clamp(..)` is summed in a different order (<= 1 ulp, only with several lights).
 #pragma once
 #define CUR_IDLE ((int)0x80000000)
 #define CUR_DONE ((int)0x80000001)
 #define CUR_POP  ((int)0x80000002)   // keeps popping at the next NODE trip
+#define CUR_FIN  ((int)0x80000003)   // path ended on a miss: owes its final sample = F(att * background(rd)); written in the next refill step
+#define CUR_FIN0 ((int)0x80000004)   // path ran out of depth: the same along the PRIMARY ray (Trace.hs:22), regenerated there
+#define CUR_SPECIAL_MAX CUR_FIN0     // a cur above this value (as unsigned) is a leaf reference
 #ifndef RT_SPECULATE
 #define RT_SPECULATE 1      // 1: a lane that reaches a leaf postpones it and keeps traversing until it holds a second one
 #endif
@@ -237,6 +241,29 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
     cur = (p_) ? CUR_POP : cur;                                                      \
   } while (0)
 
+  // Path end (Trace.hs:22,25): the sample is F(att * background) with the pending clamp function F of the record.  Lanes do
+  // not run this where their path ends (SHADE) but park as CUR_FIN / CUR_FIN0 and run it together at the next refill step:
+  // a finished lane would wait there for a new item anyway, and the block - the camera ray regenerated for ray0, the sky
+  // lookup - is then executed once for >= RT_REFILL_MIN lanes instead of once per SHADE trip for the ~14 that end in it.
+  auto finish_paths = [&]() {
+    const bool fin = cur == CUR_FIN || cur == CUR_FIN0;
+    if (fin) {
+      RT_COLD_ARGS();
+      d3 bgdir = rd;
+      if (cur == CUR_FIN0) {                             // depth ran out: background along the PRIMARY ray, regenerated
+        const int2 sb = rec_ldi(lrec, LR_SB);
+        d3 o_;
+        camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)sb.x, o_, bgdir);
+      }
+      const d3 att = rec_ld(lrec, LR_ATT), fa = rec_ld(lrec, LR_FA), fl = rec_ld(lrec, LR_FL), fh = rec_ld(lrec, LR_FH);
+      const d3 T = att * background(sc, bgdir);
+      const d3 R = clamp3(T + fa, fl, fh);
+      double *o_ = fr.samples + 3 * (size_t)item;
+      o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
+      cur = CUR_IDLE;
+    }
+  };
+
   // Gives every idle lane its next item.  All lanes of the wave run this (uniform control flow).
   // A chunk is fr.chunk CONSECUTIVE items (samples of neighbouring pixels keep a wave's rays in the same part of the
   // tree: mixing image regions inside a chunk cost 5 % of throughput).  Its size is set per launch from the items each
@@ -311,23 +338,40 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 #else
   constexpr bool TIMERS = STATS;
 #endif
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = TIMERS ? clock64() : 0ull;   // vote, node, prim, shade, refill
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = TIMERS ? clock64() : 0ull;   // vote, node, prim, shade, refill; 5..11: SHADE's sub-blocks (RT_TIMERS)
 #define RT_TICK(k) do { if (TIMERS) { const unsigned long long n_ = clock64(); tacc[k] += n_ - tlast; tlast = n_; } } while (0)
+#ifdef RT_TIMERS
+#define RT_TICK_SH(k) RT_TICK(k)
+#else
+#define RT_TICK_SH(k) do { } while (0)
+#endif
+// census of SHADE's sub-blocks (STATS variant): lanes that ran block k, and trips in which any lane did
+#define RT_SH_COUNT(k, cond) do { if (STATS) { const unsigned long long m_ = __ballot(cond); if (cond) { st[STAT_SH_L0 + (k)]++; if (lane == __ffsll((long long)m_) - 1) st[STAT_SH_W0 + (k)]++; } } } while (0)
   for (;;) {
-    if (!exhausted && __popcll(__ballot(cur == CUR_IDLE)) >= RT_REFILL_MIN) {   // all 64 idle at the start
-      RT_TICK(0);
-      refill();
-      RT_TICK(4);
+    {
+      const unsigned long long m_fin = __ballot(cur == CUR_FIN || cur == CUR_FIN0);
+      const int n_wait = __popcll(m_fin | __ballot(cur == CUR_IDLE));           // all 64 idle at the start
+      // finish + refill once enough lanes wait for it (when nothing else is left in the wave all 64 do, so the last paths are never stranded)
+      static_assert(RT_REFILL_MIN <= 64, "a wave whose lanes all wait must pass the threshold");
+      if (n_wait >= RT_REFILL_MIN && (m_fin != 0ull || !exhausted)) {
+        RT_TICK(0);
+        RT_MARK("FINISH_BEGIN");
+        if (m_fin != 0ull) finish_paths();
+        RT_MARK("REFILL_BEGIN");
+        if (!exhausted) refill();
+        RT_MARK("REFILL_DONE");
+        RT_TICK(4);
+      }
     }
-    const bool cur_leaf = (uint32_t)cur > (uint32_t)CUR_POP;
+    const bool cur_leaf = (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX;
     const bool at_node = cur >= 0 || cur == CUR_POP || (SPEC && cur_leaf && pend == 0 && sp > 0);
     const bool at_leaf = cur_leaf || (SPEC && pend != 0);
     const bool is_done = cur == CUR_DONE && !(SPEC && pend != 0);
     const int n_node = __popcll(__ballot(at_node));
     const int n_leaf = __popcll(__ballot(at_leaf));
     const int n_done = __popcll(__ballot(is_done));
-    const int n_act = SPEC ? __popcll(__ballot(cur != CUR_IDLE)) : n_node + n_leaf + n_done;
-    if (n_act == 0) break;                                 // nothing in flight and the refill found nothing: frame done
+    const int n_act = SPEC ? __popcll(__ballot(cur != CUR_IDLE && cur != CUR_FIN && cur != CUR_FIN0)) : n_node + n_leaf + n_done;
+    if (n_act == 0) break;                                 // nothing in flight (every waiting lane was finished above) and the refill found nothing: frame done
     if (STATS && lane == 0) st[STAT_LIVE] += (uint32_t)n_act;
 
     if (n_done * RT_SHADE_DEN >= n_act * RT_SHADE_NUM || n_node + n_leaf == 0) {
@@ -343,7 +387,6 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         bool need_scatter = false, need_finish = false;
         double q_tmax = RT_TMAX;
         bool need_ray0 = false;                              // background along the PRIMARY ray (depth exhausted, Trace.hs:22)
-        d3 bgdir = rd;
         // ---- All memory this trip can need is requested up front, in two rounds of independent loads, instead of one
         // dependent round trip per use: SHADE is latency bound (records and scene compete for 4 MB of L2 per XCD).
         // Round 1: the whole record and the header of the hit primitive.
@@ -367,7 +410,11 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           }
           M = sc.mats[(is_h || anyhit) ? pkm.x : 0];
         }
+        RT_MARK("SH_LOADS_END");
+        RT_TICK_SH(5);
         const bool hit_tri = ((uint32_t)pkm.y & DPRIM_KIND_MASK) == RT_PRIM_TRIANGLE;
+        RT_SH_COUNT(0, !anyhit && best >= 0);
+        RT_SH_COUNT(1, anyhit && best < 0);
         if (!anyhit) {
           if (best < 0) {                                    // Trace.hs:25: background along the current ray
             need_finish = true;
@@ -396,7 +443,10 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             if (STATS) st[STAT_SHADED]++;
             if (sc.n_lights > 0) li = sc.n_lights - 1; else need_scatter = true;
           }
-        } else {
+        }
+        RT_MARK("SH_HIT_END");
+        RT_TICK_SH(6);
+        if (anyhit) {
           if (best < 0) {                                    // unblocked: Light.hs:36-38 / :48-49
             RT_COLD_ARGS();
             const DLight L = sc.lights[li];
@@ -419,6 +469,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           --li;
           if (li < 0) need_scatter = true;
         }
+        RT_MARK("SH_LIGHT_END");
+        RT_TICK_SH(7);
+        RT_SH_COUNT(2, !need_scatter && !need_finish);
         if (!need_scatter && !need_finish) {                 // shadow ray towards light li (Light.hs:26-30, 39-42)
           RT_COLD_ARGS();
           // FAST: a light the surface faces away from adds max(0, n.l) * ... = 0 whether or not it is visible
@@ -440,6 +493,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             if (--li < 0) { need_scatter = true; q_tmax = RT_TMAX; break; }   // the bounce ray follows in this trip
           }
         }
+        RT_MARK("SH_SHADOWSETUP_END");
+        RT_TICK_SH(8);
+        RT_SH_COUNT(3, need_scatter);
         if (need_scatter) {                                  // Trace.hs:27-76
           RT_COLD_ARGS();
           const bool front = (hitp & HITP_FRONT) != 0;
@@ -476,19 +532,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           li = -1;
           if (sb.y >= fr.maxb) { need_ray0 = true; need_finish = true; }         // depth 0: background along ray0, :22
         }
-        if (need_finish) {                                   // path end: its radiance goes to the per-sample buffer
-          RT_COLD_ARGS();
-          if (need_ray0) {                                   // depth ran out: background along the PRIMARY ray (Trace.hs:22), regenerated
-            d3 o_;
-            camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)sb.x, o_, bgdir);
-          }
-          const d3 T = att * background(sc, bgdir);
-          const d3 R = clamp3(T + fa, fl, fh);
-          double *o_ = fr.samples + 3 * (size_t)item;
-          o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
-          cur = CUR_IDLE;                                    // the lane is free: it pulls its next item in the refill below
-        }
-        if (cur != CUR_IDLE) { RT_COLD_ARGS(); RT_BEGIN_QUERY(q_tmax); }
+        RT_MARK("SH_SCATTER_END");
+        RT_TICK_SH(9);
+        RT_SH_COUNT(4, need_finish);
+        if (need_finish) cur = need_ray0 ? CUR_FIN0 : CUR_FIN;   // path end: the sample is written in the next refill step (finish_paths)
+        RT_MARK("SH_FINISH_END");
+        RT_TICK_SH(10);
+        if (!need_finish) { RT_COLD_ARGS(); RT_BEGIN_QUERY(q_tmax); }
+        RT_TICK_SH(11);
       }
       RT_MARK("SHADE_END");
       RT_TICK(3);
@@ -502,7 +553,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       for (int it = 0; it < NODE_UNROLL; ++it) {
         bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
         if (SPEC) {                                          // postpone a freshly reached leaf and go on with the next stack entry
-          const bool spec = (uint32_t)cur > (uint32_t)CUR_POP && pend == 0 && sp > 0;
+          const bool spec = (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX && pend == 0 && sp > 0;
           pend = spec ? cur : pend;
           pp = pp || spec;
         }
@@ -560,7 +611,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 #pragma unroll
       for (int it = 0; it < PRIM_UNROLL; ++it) {
         const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
-        const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_POP;
+        const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX;
         const int pi = ~(use_p ? pend : cur);
         // lanes not in a leaf read primitive 0 (always present) and discard the result: see the NODE body
         const DPrim P = *(const DPrim *)((const char *)sc.tprims + (size_t)((uint32_t)(isl ? pi : 0) * 80u));
@@ -633,7 +684,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
 #undef RT_POP2
 
   if (TIMERS && lane == 0) {
-    for (int k = 0; k < 5; ++k) atomicAdd(fr.stats + STAT_T_VOTE + k, tacc[k]);
+    for (int k = 0; k < 12; ++k) atomicAdd(fr.stats + STAT_T_VOTE + k, tacc[k]);
   }
 #ifdef RT_TIMERS
   if (fr.dbg && lane == 0) {                               // per wave: start, pool exhausted, end (100 MHz wall clock), chunks taken

@@ -317,6 +317,41 @@ def c4_blob63k(width=1920, height=1080, spp=100, **kw):
     return blob_scene("c4_blob63k", 166, 192, width, height, spp, **kw)
 
 
+def sunset_sky(w=2048, h=1024, seed=7):
+    """A synthetic equirect HDR sky (RT_SKY_RGBF, row 0 = zenith) standing in for the .hdr obli.json names
+    (configurations/obli.json `skyTexture`: the author's file is not in the reference, .gitignore:28-33): warm horizon,
+    blue zenith, dark ground, a sun disk of radiance ~60 and seeded texel noise, so neighbouring texels differ and the
+    nearest-texel addressing (SkySphere.hs:37-41) is exercised.  With a sky every terminating path runs sampleSkySphere
+    (normalize, atan2, asin, one texel fetch) instead of returning the solid background (Trace.hs:78-83)."""
+    rng = np.random.default_rng(seed)
+    v = (np.arange(h, dtype=np.float64) + 0.5) / h                      # 0 = zenith, 1 = nadir
+    u = (np.arange(w, dtype=np.float64) + 0.5) / w
+    elev = (0.5 - v)[:, None] * np.pi                                   # +pi/2 .. -pi/2
+    az = (u[None, :] - 0.5) * 2 * np.pi
+    up = np.clip(np.sin(elev), 0.0, 1.0)
+    horizon = np.exp(-np.abs(elev) * 6.0)
+    img = np.empty((h, w, 3), np.float64)
+    img[..., 0] = 0.25 + 0.15 * up + 0.9 * horizon + 0 * az
+    img[..., 1] = 0.35 + 0.25 * up + 0.45 * horizon + 0 * az
+    img[..., 2] = 0.55 + 0.45 * up + 0.15 * horizon + 0 * az
+    img[elev[:, 0] < 0] *= 0.35                                          # ground half
+    sun_el, sun_az = 0.18, 0.9
+    ang = np.arccos(np.clip(np.sin(elev) * np.sin(sun_el) + np.cos(elev) * np.cos(sun_el) * np.cos(az - sun_az), -1, 1))
+    img += (60.0 * (ang < 0.03) + 2.5 * np.exp(-ang * 9.0))[..., None] * np.array([1.0, 0.85, 0.6])
+    img *= 1.0 + 0.04 * rng.standard_normal((h, w, 1))
+    return "rgbf", np.ascontiguousarray(np.clip(img, 0.0, None).astype(np.float32))
+
+
+def c4_shipped(width=1920, height=1080, spp=100, sky_size=(2048, 1024), **kw):
+    """The metric config AS SHIPPED in configurations/obli.json: bvhMaxDepth 10 (obli.json:41: 1,024 leaves of ~62
+    triangles in the reference's tree) and an HDR sky texture (obli.json `skyTexture`; synthetic here, see sunset_sky),
+    which takes priority over the solid background (Trace.hs:78-83).  bench.py's default workload."""
+    kw.setdefault("bvh_max_depth", 10)
+    s = blob_scene("c4_blob63k_shipped", 166, 192, width, height, spp, **kw)
+    s.sky = sunset_sky(*sky_size)
+    return s
+
+
 def c5_multi(width=3840, height=2160, spp=256, copies=32, **kw):
     """C5: 32 copies of the C4 blob as separate objFiles entries (2,029,184 + 20 triangles), 4K, 256 spp."""
     s = blob_scene("c5_multi", 166, 192, width, height, spp, copies=copies, **kw)

@@ -1,6 +1,6 @@
 """Committed golden vectors (tests/golden/*.npz, made by tools/make_golden.py from the CPU oracle).
 CPU: the oracle still reproduces them bit-for-bit (guards the checker against drift).
-GPU (-m gpu): the HIP core matches the same files to the north_star tolerances."""
+GPU (-m gpu): the HIP core matches the same files: ids and 8-bit frame equal, radiance and colour within 1e-12."""
 import os
 
 import numpy as np
@@ -34,10 +34,8 @@ def test_gpu_matches_golden(need_gpu, name, spec, over):
     s = api.GpuScene(spec)
     res, _ = s.render(**over)
     s.close()
-    d = np.abs(res["radiance"] - g["radiance"]).max(axis=2)
-    if "det" in name:                       # deterministic: ids >= 99.99 %, radiance within 1e-4 abs
-        ids = res["prim_id"] == g["prim_id"]
-        assert ids.mean() >= 0.9999 and d[ids].max() <= 1e-4
-    else:                                   # shared counter-based RNG: path-for-path within 1e-4 on >= 99.5 % of pixels
-        assert (d <= 1e-4).mean() >= 0.995
-        assert np.sqrt(np.mean((res["color"] - g["color"]) ** 2)) <= 5e-3
+    # the committed vectors are oracle outputs; the kernel matches them path for path (see tests/test_gpu_parity.py)
+    assert (res["prim_id"] == g["prim_id"]).all()
+    assert np.abs(res["radiance"] - g["radiance"]).max() <= 1e-12
+    assert np.abs(res["color"] - g["color"]).max() <= 1e-12
+    assert (res["rgb8"] == g["rgb8"]).all()

@@ -4,8 +4,9 @@ kernel share the counter-based RNG keyed by (pixel, sample, bounce), so every pi
 comparable path-for-path with the oracle's value for that pixel.  Plus the size-independent properties: the frame
 is bit-identical for every tile sharding and for every split over sample-buffer launches.
 
-Tolerance: the north_star bar is 1e-4 absolute on radiance; the library is built without FP contraction, so the
-measured difference is ~1e-15 and the tests also pin that (<= 1e-9 on >= 99.9 % of the compared pixels)."""
+Tolerance: the north_star bar is 1e-4 absolute on radiance; the library is built without FP contraction and the
+measured difference is ~1e-15, so the tests enforce that: primitive ids equal on every compared pixel, radiance within
+1e-12 (relative to max(1, |radiance|): the HDR sky reaches 70).  Exceptions would have to be listed by pixel."""
 import numpy as np
 import pytest
 
@@ -16,27 +17,24 @@ from raytracer_amd import dist as rdist
 pytestmark = pytest.mark.gpu
 
 
-def compare_rows(spec, res, rows, n_threads=16):
+def compare_rows(spec, res, rows, n_threads=16, allow=()):
     o = O.OracleScene(spec)
-    worst, n_bad, n_px = 0.0, 0, 0
+    worst = 0.0
     for r in rows:
         ref = o.render(rows=(r, r + 1), n_threads=n_threads, want_ids=True)
-        d = np.abs(res["radiance"][r] - ref["radiance"][r]).max(axis=1)
         assert np.isfinite(ref["radiance"][r]).all()
+        d = (np.abs(res["radiance"][r] - ref["radiance"][r]) / np.maximum(1.0, np.abs(ref["radiance"][r]))).max(axis=1)
+        ids_bad = res["prim_id"][r] != ref["prim_id"][r]
+        bad = [c for c in np.nonzero((d > 1e-12) | ids_bad)[0].tolist() if (r, c) not in allow]
+        assert not bad, f"row {r}: {len(bad)} pixels differ (ids or radiance beyond 1e-12), first columns {bad[:8]}, worst {d.max():.3e}"
         worst = max(worst, float(d.max()))
-        n_bad += int((d > 1e-9).sum())
-        n_px += d.size
-        assert (d <= 1e-4).mean() >= 0.999, f"row {r}: only {(d <= 1e-4).mean():.5f} within 1e-4"
-        ids_ok = res["prim_id"][r] == ref["prim_id"][r]
-        assert ids_ok.mean() >= 0.999, f"row {r}: primitive ids {ids_ok.mean():.5f}"
     o.close()
-    assert n_bad <= 1e-3 * n_px, f"{n_bad} of {n_px} pixels differ by more than 1e-9 (worst {worst:.3e})"
     return worst
 
 
 @pytest.mark.timeout(300)
 def test_c4_full_size_rows_match_oracle(need_gpu):
-    spec = scenes.c4_blob63k()                                 # 1920x1080, 100 spp, maxBounces 5: the bench workload
+    spec = scenes.c4_shipped()                                 # 1920x1080, 100 spp, maxBounces 5, bvhMaxDepth 10, HDR sky: the bench workload
     assert (spec.width, spec.height, spec.spp) == (1920, 1080, 100)
     g = api.GpuScene(spec, n_threads=8)
     res, st = g.render(want=("radiance", "prim_id"), collect_stats=1)
@@ -48,7 +46,7 @@ def test_c4_full_size_rows_match_oracle(need_gpu):
 
 def test_c4_full_size_sharding_is_bit_identical(need_gpu):
     import torch
-    spec = scenes.c4_blob63k()
+    spec = scenes.c4_shipped()
     W, H, world = spec.width, spec.height, 8
     g = api.GpuScene(spec, n_threads=8)
     full, _ = g.render(want=("color",))

@@ -1,11 +1,12 @@
 """GPU parity: the HIP render core (through the C ABI) against the CPU oracle on the same seeded inputs.
 
-Tolerances (BASELINE.json north_star): deterministic configs (antialiasing off, maxBounces <= 1):
-primary-hit primitive ids equal on >= 99.99 % of pixels, radiance within 1e-4 abs.  Because oracle and
-GPU share the counter-based RNG (Philox4x32-10 keyed by pixel/sample/bounce), the stochastic configs
-are ALSO compared path-for-path: the same tolerance must hold on >= 99.9 % of pixels (a path can
-legitimately diverge where an FMA-rounded test flips a discrete decision) and the mean images must
-agree to RMSE <= 2e-3.
+north_star's bar: deterministic configs (antialiasing off, maxBounces <= 1): primary-hit primitive ids equal on
+>= 99.99 % of pixels, radiance within 1e-4 abs; stochastic configs: mean images.  What is ENFORCED here is the bar the
+library actually meets, so that a regression of one pixel in a frame fails: oracle and GPU share the counter-based RNG
+(Philox4x32-10 keyed by pixel / sample / bounce) and librtcore is built without FP contraction, so every config -
+stochastic ones included - is compared path for path: primitive ids equal on EVERY pixel, radiance and colour within
+1e-12 abs (the kernel re-associates the additions of the nested clamp, DESIGN.md section 5: measured <= 4.4e-16
+relative), 8-bit frame equal.  A pixel that may legitimately differ has to be listed by (row, col) in `allow`.
 """
 import numpy as np
 import pytest
@@ -14,6 +15,8 @@ from oracle import oracle as O
 from raytracer_amd import api, scenes
 
 pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
 
 
 def render_both(spec, want=("color", "radiance", "rgb8", "prim_id"), **over):
@@ -26,24 +29,23 @@ def render_both(spec, want=("color", "radiance", "rgb8", "prim_id"), **over):
     return res, ref, st
 
 
-def check_deterministic(res, ref):
-    ids_ok = (res["prim_id"] == ref["prim_id"])
-    assert ids_ok.mean() >= 0.9999, f"primitive-id match {ids_ok.mean():.6f}"
-    d = np.abs(res["radiance"] - ref["radiance"]).max(axis=2)
-    assert d[ids_ok].max() <= 1e-4, f"radiance max |d| {d[ids_ok].max():.3e}"
-    dc = np.abs(res["color"] - ref["color"]).max(axis=2)
-    assert dc[ids_ok].max() <= 1e-4
-    q = np.abs(res["rgb8"].astype(int) - ref["rgb8"].astype(int))
-    assert (q[ids_ok] <= 1).all()
-    assert (q[ids_ok] == 0).mean() > 0.999
+def check_exact(res, ref, allow=()):
+    """ids equal everywhere, radiance / colour within TOL, 8-bit frame equal; `allow`: (row, col) pixels exempted."""
+    keep = np.ones(res["prim_id"].shape, bool)
+    for r, c in allow:
+        keep[r, c] = False
+    bad = np.argwhere((res["prim_id"] != ref["prim_id"]) & keep)
+    assert len(bad) == 0, f"{len(bad)} primitive ids differ, first at (row, col) {bad[:5].tolist()}"
+    for k in ("radiance", "color"):
+        d = np.abs(res[k] - ref[k]).max(axis=2)
+        bad = np.argwhere(~(d <= TOL) & keep)
+        assert len(bad) == 0, f"{k}: {len(bad)} pixels beyond {TOL}, worst {np.nanmax(d):.3e} at {bad[:5].tolist()}"
+    bad = np.argwhere((res["rgb8"] != ref["rgb8"]).any(axis=2) & keep)
+    assert len(bad) == 0, f"8-bit frame differs at {bad[:5].tolist()}"
 
 
-def check_stochastic(res, ref, frac=0.999, rmse=2e-3):
-    d = np.abs(res["radiance"] - ref["radiance"]).max(axis=2)
-    ok = d <= 1e-4
-    assert ok.mean() >= frac, f"only {ok.mean():.5f} of pixels agree path-for-path"
-    e = np.sqrt(np.mean((res["color"] - ref["color"]) ** 2))
-    assert e <= rmse, f"mean-image RMSE {e:.3e}"
+check_deterministic = check_exact
+check_stochastic = check_exact
 
 
 @pytest.mark.parametrize("box_precision", [0, 1, 2])     # own SAH tree / reference tree, exact FP64 slab test / reference tree, FP32 boxes
@@ -66,6 +68,14 @@ def test_c4_shipped_depth10_variant(need_gpu):
     spec = scenes.c4_blob63k(width=256, height=144, spp=1, antialiasing=False, max_bounces=1, bvh_max_depth=10)
     res, ref, _ = render_both(spec)
     check_deterministic(res, ref)
+
+
+def test_c4_as_shipped_sky_and_depth10(need_gpu):
+    # the bench workload (obli.json as shipped): bvhMaxDepth 10 and an HDR sky that every terminating path samples
+    spec = scenes.c4_shipped(width=192, height=108, spp=4, sky_size=(256, 128))
+    res, ref, _ = render_both(spec)
+    check_stochastic(res, ref)
+    assert res["radiance"].max() > 1.5                        # the sky is in use: the solid background would cap a primary miss at 1.0
 
 
 def test_c2_stochastic_glass_metal(need_gpu):
@@ -93,9 +103,8 @@ def test_fp32_boxes_equal_fp64_boxes(need_gpu):
     b, _ = g.render(box_precision=1)
     for mode in (0, 2):
         a, _ = g.render(box_precision=mode)
-        same = (np.abs(a["radiance"] - b["radiance"]).max(axis=2) <= 1e-9)
-        assert same.mean() >= 0.9995, mode
-        assert (a["prim_id"] == b["prim_id"]).mean() >= 0.9999, mode
+        assert np.abs(a["radiance"] - b["radiance"]).max() <= TOL, mode
+        assert (a["prim_id"] == b["prim_id"]).all(), mode
     g.close()
 
 
@@ -119,6 +128,24 @@ def test_sky_sphere(need_gpu, fmt):
     spec.sky = scenes.sky_gradient_texture(fmt=fmt)
     res, ref, _ = render_both(spec)
     check_stochastic(res, ref)
+
+
+@pytest.mark.parametrize("look", [(1, 0.2, 0.1), (-1, 0.1, 0.0), (-1, 0.0, 1e-9), (0.05, 1, 0.02), (0.0, -1, 0.03), (0.3, -0.2, -1)])
+def test_sky_texel_sweep(need_gpu, look):
+    """The device finds the sky texel with threshold tables instead of atan2 / asin (sky_texel, rt_kernels.h): a frame of
+    primary misses - one tiny far sphere, maxBounces 1, 120 degree field of view - looks along +-x (the u = 0 / 1 seam
+    at -x), +-y (the poles) and -z, and every pixel must be the oracle's texel."""
+    spec = scenes.c1_testing(width=640, height=360, spp=1, antialiasing=False, max_bounces=1)
+    spec.obj_meshes = []
+    spec.config_objects = [("sphere", [500.0, 900.0, 700.0], 0.001, None)]
+    spec.lights = []
+    spec.camera = {"lookFrom": [0.0, 0.0, 0.0], "lookAt": [float(x) for x in look], "vUp": [0.0, 0.0, 1.0] if abs(look[1]) == 1 else [0.0, 1.0, 0.0],
+                   "vfov": 120.0, "aperture": 0.0, "focusDist": 1.0}
+    rng = np.random.default_rng(5)
+    spec.sky = ("rgbf", rng.uniform(0.0, 4.0, size=(193, 517, 3)).astype(np.float32))      # odd sizes, every texel different
+    res, ref, _ = render_both(spec)
+    assert (ref["prim_id"] == -1).all()
+    assert np.array_equal(res["radiance"], ref["radiance"])
 
 
 def test_planes_and_mixed_leaves(need_gpu):
@@ -150,12 +177,9 @@ def test_ray_counters_match_oracle(need_gpu):
     o = O.OracleScene(spec)
     ref, cnt = o.render(counters=True)
     o.close()
-    agree = (np.abs(res["radiance"] - ref["radiance"]).max(axis=2) <= 1e-4).mean()
-    assert agree >= 0.999
-    # ray counts are path-structure counts: equal unless a path diverged
-    assert abs(st.rays_closest - cnt["rays_closest"]) <= 0.002 * cnt["rays_closest"]
-    assert abs(st.rays_shadow - cnt["rays_shadow"]) <= 0.002 * cnt["rays_shadow"]
-    assert abs(st.shaded_hits - cnt["shaded_hits"]) <= 0.002 * cnt["shaded_hits"]
+    assert np.abs(res["radiance"] - ref["radiance"]).max() <= TOL
+    # ray counts are path-structure counts: equal, since no path diverges
+    assert st.rays_closest == cnt["rays_closest"] and st.rays_shadow == cnt["rays_shadow"] and st.shaded_hits == cnt["shaded_hits"]
     # the kernel culls stacked nodes the reference still enters with an empty interval
     assert st.nodes_visited <= cnt["nodes_literal"]
     assert st.nodes_visited >= 0.5 * cnt["nodes_nonempty"]

@@ -4,7 +4,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import api, scenes
 w, h, spp = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1920, 1080, 16)))
-spec = scenes.c4_blob63k(width=w, height=h, spp=spp)
+spec = (scenes.c4_blob63k if os.environ.get("CENSUS_WORKLOAD") == "c4v" else scenes.c4_shipped)(width=w, height=h, spp=spp)
 g = api.GpuScene(spec, n_threads=8)
 res, st = g.render(want=("color",), collect_stats=1)
 rays = max(1, st.rays_closest + st.rays_shadow)      # 0 with the timers-only build (-DRT_TIMERS): only the time split is meaningful
@@ -22,3 +22,10 @@ if tot:
     steps = max(1, steps)
     for n, c, k in (("vote", st.cyc_vote, steps), ("node", st.cyc_node, st.sched_node_steps), ("prim", st.cyc_prim, st.sched_prim_steps), ("shade", st.cyc_shade, st.sched_shade_steps), ("refill", st.cyc_refill, st.sched_shade_steps)):
         print(f"time in {n:6s}: {100 * c / tot:5.1f} %   {c / max(1, k):8.0f} ticks per trip")
+names = ("hit", "light term", "shadow set-up", "scatter", "finish")
+for k, n in enumerate(names):
+    print(f"SHADE {n:14s}: {st.shade_lanes[k]} lanes in {st.shade_trips[k]} trips = {st.shade_lanes[k] / max(1, st.shade_trips[k]):.1f} lanes/trip, in {st.shade_trips[k] / max(1, st.sched_shade_steps):.3f} of the SHADE trips")
+det = list(st.cyc_shade_detail)
+if sum(det):
+    for n, c in zip(("loads", "hit", "light", "set-up", "scatter", "finish", "begin query"), det):
+        print(f"SHADE time in {n:12s}: {100 * c / max(1, sum(det)):5.1f} %")
