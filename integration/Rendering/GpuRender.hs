@@ -366,7 +366,9 @@ renderOnGpu config bvh materialMap skySphere cameraObj sceneLights = do
                               c_rt_scene_create desc pScene >>= check "rt_scene_create"
                               scene <- peek pScene
                               SVM.unsafeWith frame $ \pFrame -> do
-                                fillBytes out 0 sizeof_rt_output
+                                pokeByteOff out off_rt_output_radiance (nullPtr :: Ptr Double) -- not wanted: the writer needs the 8-bit frame only
+                                pokeByteOff out off_rt_output_color (nullPtr :: Ptr Double) -- (ask for this one to keep `showPixel` in Haskell)
+                                pokeByteOff out off_rt_output_prim_id (nullPtr :: Ptr Int32)
                                 pokeByteOff out off_rt_output_rgb8 pFrame
                                 fillBytes stats 0 sizeof_rt_stats
                                 rc <- c_rt_render scene cam params out stats
