@@ -1,8 +1,10 @@
 """ctypes wrapper of oracle/_build/liboracle.so — TEST INFRASTRUCTURE ONLY.
 
 May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by
-raytracer_amd/.  It only reuses raytracer_amd's ctypes struct definitions and SceneSpec (data
-classes of the public ABI), no product compute code.
+raytracer_amd/.  It reuses raytracer_amd's ctypes struct definitions and SceneSpec (data classes of
+the public ABI) and nothing else: the scene -> struct marshalling below is the checker's OWN reading
+of the reference's set-up code, written separately from raytracer_amd/api.py, so that a slip in the
+product's marshalling shows up as a GPU-vs-oracle difference instead of cancelling out.
 """
 from __future__ import annotations
 
@@ -12,8 +14,7 @@ import os
 
 import numpy as np
 
-from raytracer_amd import _ffi as F
-from raytracer_amd.api import background_of, make_lights, make_materials, make_params
+from raytracer_amd import _ffi as F          # only the ctypes struct classes of the public ABI (layout pinned by tests/test_haskell_offsets.py)
 from raytracer_amd.scenes import SceneSpec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -80,6 +81,64 @@ def _ip(a):
     return a.ctypes.data_as(F.c_int32_p)
 
 
+# ---- the checker's own scene -> struct marshalling (deliberately not shared with raytracer_amd/api.py)
+def _set3(dst, src):
+    dst[0], dst[1], dst[2] = float(src[0]), float(src[1]), float(src[2])
+
+
+def oracle_materials(spec: SceneSpec):
+    """`materials :: Maybe [(String, Material)]` -> ids 1.. in list order (assignMaterialIds, Parser/Material.hs:52-57);
+    absent optional fields stay `Nothing` = no flag bit (Rendering/Material.hs:37-46: only diffuseColor has a default)."""
+    table = (F.rt_material * max(1, len(spec.materials)))()
+    for ident, (_name, fields) in enumerate(spec.materials, start=1):
+        m = table[ident - 1]
+        m.id, m.flags = ident, 0
+        _set3(m.diffuse, fields["diffuseColor"] if "diffuseColor" in fields else (1.0, 1.0, 1.0))
+        for key, bit, setter in (("emissionColor", F.RT_MAT_HAS_EMISSION, lambda v: _set3(m.emission, v)),
+                                 ("shininess", F.RT_MAT_HAS_SHININESS, lambda v: setattr(m, "shininess", float(v))),
+                                 ("ior", F.RT_MAT_HAS_IOR, lambda v: setattr(m, "ior", float(v))),
+                                 ("transmission", F.RT_MAT_HAS_TRANSMISSION, lambda v: setattr(m, "transmission", float(v)))):
+            if fields.get(key) is not None:
+                m.flags |= bit
+                setter(fields[key])
+    return table, len(spec.materials)
+
+
+def oracle_lights(spec: SceneSpec):
+    """convertLight (Rendering/ImageGenerator.hs:137-139)."""
+    table = (F.rt_light * max(1, len(spec.lights)))()
+    for slot, light in zip(table, spec.lights):
+        point = light["tag"] == "PointLight"
+        if not point and light["tag"] != "DirectionalLight":
+            raise ValueError(f"unknown light {light['tag']}")
+        slot.kind = F.RT_LIGHT_POINT if point else F.RT_LIGHT_DIRECTIONAL
+        _set3(slot.vec, light["position"] if point else light["direction"])
+        _set3(slot.intensity, light["intensity"])
+    return table, len(spec.lights)
+
+
+def oracle_background(spec: SceneSpec):
+    """BackgroundSettings (Config.hs:40-43): Gradient color1 color2 | SolidColor color."""
+    tag = spec.background["tag"]
+    if tag == "SolidColor":
+        return F.RT_BG_SOLID, spec.background["color"], spec.background["color"]
+    if tag != "Gradient":
+        raise ValueError(f"unknown background {tag}")
+    return F.RT_BG_GRADIENT, spec.background["color1"], spec.background["color2"]
+
+
+def oracle_params(spec: SceneSpec, **over) -> F.rt_params:
+    """ImageSettings + RaytracerSettings (Config.hs:29-37, 58-64) + the RNG key."""
+    p = F.rt_params(width=spec.width, height=spec.height, samples_per_pixel=spec.spp, antialiasing=int(bool(spec.antialiasing)),
+                    max_bounces=spec.max_bounces, rr_start_bounce=0, exposure=spec.exposure, gamma=spec.gamma, seed=spec.seed,
+                    collect_stats=0, box_precision=0)
+    for name, value in over.items():
+        if not hasattr(p, name):
+            raise AttributeError(name)
+        setattr(p, name, value)
+    return p
+
+
 def default_camera(cam: dict, aspect: float) -> F.rt_camera:
     out = F.rt_camera()
     lf, la, up = _d(cam["lookFrom"]), _d(cam["lookAt"]), _d(cam["vUp"])
@@ -93,9 +152,9 @@ class OracleScene:
         self.spec = spec
         kind, data, mat = spec.all_objects()
         self.n_objs = len(kind)
-        mats, nm = make_materials(spec)
-        lights, nl = make_lights(spec)
-        bgk, c1, c2 = background_of(spec)
+        mats, nm = oracle_materials(spec)
+        lights, nl = oracle_lights(spec)
+        bgk, c1, c2 = oracle_background(spec)
         c1, c2 = _d(c1), _d(c2)
         sky_fmt, sw, sh, sp = F.RT_SKY_NONE, 0, 0, None
         if spec.sky is not None:
@@ -128,7 +187,7 @@ class OracleScene:
     def render(self, rows=None, n_threads=8, counters=False, camera=None, want_ids=True, row_stride=1, **param_over):
         """Renders file rows rows[0], rows[0]+row_stride, ... < rows[1] (default: all).  Returns dict of full-frame arrays
         (unrendered rows are NaN / -2) and, with counters=True, the traversal counters."""
-        p = make_params(self.spec, **param_over)
+        p = oracle_params(self.spec, **param_over)
         W, H = p.width, p.height
         r0, r1 = rows if rows is not None else (0, H)
         rad = np.full((H, W, 3), np.nan); col = np.full((H, W, 3), np.nan)
