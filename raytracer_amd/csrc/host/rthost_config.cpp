@@ -58,11 +58,19 @@ struct JParser {
     if (c == 'f' && end - p >= 5 && !strncmp(p, "false", 5)) { p += 5; v.kind = JValue::Bool; v.b = false; return true; }
     if (c == 'n' && end - p >= 4 && !strncmp(p, "null", 4)) { p += 4; v.kind = JValue::Null; return true; }
     if (c == '-' || (c >= '0' && c <= '9')) {
+      // the JSON number grammar (what aeson accepts): -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?  - scanned first,
+      // so that strtod's extras (hex floats, "inf", "nan", a leading '+') are rejected as the reference rejects them
+      const char *q = p;
+      auto digits = [&]() { const char *q0 = q; while (q < end && *q >= '0' && *q <= '9') ++q; return q > q0; };
+      if (*q == '-') ++q;
+      if (q < end && *q == '0') ++q; else if (!digits()) return fail_("bad number");
+      if (q < end && *q == '.') { ++q; if (!digits()) return fail_("bad number"); }
+      if (q < end && (*q == 'e' || *q == 'E')) { ++q; if (q < end && (*q == '+' || *q == '-')) ++q; if (!digits()) return fail_("bad number"); }
       char *e = nullptr;
-      std::string tmp(p, std::min<size_t>(end - p, 64));
+      std::string tmp(p, (size_t)(q - p));
       double d = strtod(tmp.c_str(), &e);
-      if (e == tmp.c_str()) return fail_("bad number");
-      p += e - tmp.c_str();
+      if (e != tmp.c_str() + tmp.size()) return fail_("bad number");
+      p = q;
       v.kind = JValue::Num; v.num = d;
       return true;
     }
@@ -279,7 +287,14 @@ bool parse_mtl(const std::string &content, std::map<std::string, Mat> &out, std:
     else if (w[0] == "Ns" && need(2)) { cur.hasShininess = true; if (!rd(1, cur.shininess)) return false; }
     else if (w[0] == "Ni" && need(2)) { cur.hasIor = true; if (!rd(1, cur.ior)) return false; }
     else if (w[0] == "d" && need(2)) { double t; if (!rd(1, t)) return false; }
-    else if (w[0] == "illum" && need(2)) { double t; if (!rd(1, t) || t != std::floor(t)) { err = "Prelude.read: no parse (illum)"; return false; } hasIllum = true; illum = (int)t; }
+    else if (w[0] == "illum" && need(2)) {   // `read :: Int` (Parser/Material.hs): optional '-', decimal digits, nothing else ("2.0" is no parse)
+      const std::string &tk = w[1];
+      size_t k = (tk.size() > 1 && tk[0] == '-') ? 1 : 0;
+      bool ok = tk.size() > k;
+      for (size_t q = k; q < tk.size(); ++q) ok = ok && tk[q] >= '0' && tk[q] <= '9';
+      if (!ok) { err = "Prelude.read: no parse (illum)"; return false; }
+      hasIllum = true; illum = atoi(tk.c_str());
+    }
   }
   if (have) finalize();
   return true;
@@ -483,12 +498,15 @@ int rth_config_load(const char *json_path, rth_config **out) {
     };
     std::vector<Tok> w;
     std::vector<double> verts;
+    std::vector<char> bad_vert;
     const char *p = tb, *lb, *le;
     while (next_line(p, lb, le)) {
       if (le - lb < 2 || lb[0] != 'v' || lb[1] != ' ') continue;                 // "v " `isPrefixOf` l, :19
       split_words(lb, le, w);
-      double x, y, z;
-      if (w.size() != 4 || !tok_double(w[1], x) || !tok_double(w[2], y) || !tok_double(w[3], z)) { o.err = "Invalid vertex format in .obj file"; return; }   // :40
+      double x = 0, y = 0, z = 0;
+      // `verts` is a lazy list in the reference: a malformed "v" line (:39-40) only raises when a face references it (:52-54)
+      const bool ok = w.size() == 4 && tok_double(w[1], x) && tok_double(w[2], y) && tok_double(w[3], z);
+      bad_vert.push_back(ok ? 0 : 1);
       verts.push_back(x); verts.push_back(y); verts.push_back(z);
     }
     const long nv = (long)verts.size() / 3;
@@ -513,6 +531,7 @@ int rth_config_load(const char *json_path, rth_config **out) {
         long ix;
         if (!tok_long(tok, ix)) { o.err = "Prelude.read: no parse (face index '" + std::string(tok.b, tok.e) + "')"; return; }
         if (ix < 1 || ix > nv) { o.err = "Prelude.!!: index out of range (face index " + std::to_string(ix) + ", " + std::to_string(nv) + " vertices)"; return; }
+        if (bad_vert[ix - 1]) { o.err = "Invalid vertex format in .obj file"; return; }                                // :40, forced here
         fv.push_back(ix - 1);
       }
       auto emit = [&](long a, long b, long c) {

@@ -18,8 +18,13 @@ bool ends_with(const std::string &s, const char *suf) {
   size_t n = strlen(suf);
   return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
+// RGBE -> float.  PARITY UNPINNED: the reference decodes through JuicyPixels' readImage, whose source is not part of the
+// reference checkout and cannot be imported here, and the reference holds no decoded fixture.  This follows JuicyPixels'
+// Codec.Picture.HDR.toFloat as recalled - (mantissa + 0.5) * 2^(e - 136) for every exponent, with no special case for
+// e = 0 (which yields a denormal ~1e-41 rather than 0: invisible next to the 1e-12 of the parity tests) - and the only
+// thing tests/test_config_loader.py pins is this formula itself.  If JuicyPixels truncates instead (mantissa * 2^(e - 136))
+// every texel here is half a mantissa step too bright: 0.2-0.4 % on the dominant channel.
 void rgbe_to_float(const unsigned char *p, float *out) {
-  if (p[3] == 0) { out[0] = out[1] = out[2] = 0.0f; return; }
   float f = std::ldexp(1.0f, (int)p[3] - (128 + 8));
   out[0] = (p[0] + 0.5f) * f; out[1] = (p[1] + 0.5f) * f; out[2] = (p[2] + 0.5f) * f;
 }

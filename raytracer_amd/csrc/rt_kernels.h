@@ -457,18 +457,21 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_resolve(const KFrame fr) {
   }
 }
 
-// Tiles of tile row y that belong to `rank` of `world`: those with (x + y) mod world == rank, x in [0, tiles_x).
-__host__ __device__ inline int tiles_in_row(int tiles_x, int y, int rank, int world) {
-  const int a = ((rank - y % world) + world) % world;                  // the first such x
+// Tiles of tile row y that belong to `rank` of `world`: those with (x + skew * y) mod world == rank, x in [0, tiles_x).
+__host__ __device__ inline int tile_first_x(int y, int rank, int world, int skew) {
+  return (int)((((long long)rank - (long long)skew * y) % world + world) % world);
+}
+__host__ __device__ inline int tiles_in_row(int tiles_x, int y, int rank, int world, int skew) {
+  const int a = tile_first_x(y, rank, world, skew);
   return a < tiles_x ? (tiles_x - 1 - a) / world + 1 : 0;
 }
 // A rank's tile list (rt_tile_list's order: increasing y * tiles_x + x), written on the device: one thread per tile row.
-__global__ void k_make_tiles(int tiles_x, int tiles_y, int rank, int world, int32_t *out) {
+__global__ void k_make_tiles(int tiles_x, int tiles_y, int rank, int world, int skew, int32_t *out) {
   const int y = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (y >= tiles_y) return;
   int base = 0;
-  for (int q = 0; q < y; ++q) base += tiles_in_row(tiles_x, q, rank, world);
-  for (int x = ((rank - y % world) + world) % world; x < tiles_x; x += world) out[base++] = y * tiles_x + x;
+  for (int q = 0; q < y; ++q) base += tiles_in_row(tiles_x, q, rank, world, skew);
+  for (int x = tile_first_x(y, rank, world, skew); x < tiles_x; x += world) out[base++] = y * tiles_x + x;
 }
 
 __global__ void k_untile(const int32_t *tiles, int n_tiles, int tiles_x, int W, int H, int n_comp,

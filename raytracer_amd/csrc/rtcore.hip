@@ -122,6 +122,12 @@ template <typename T> int dev_upload(T **dst, const T *src, size_t n) {
 
 }  // namespace
 
+// Tile (tx, ty) belongs to rank (tx + skew * ty) mod world.  skew = 1 unless RT_TILE_SKEW says otherwise (experiment knob of
+// tools/rank_timing.py; raytracer_amd/dist.py reads the same variable): read once, so every list of a process agrees.
+static int tile_skew() {
+  static const int v = []() { const char *e = getenv("RT_TILE_SKEW"); const int k = e ? atoi(e) : 1; return k > 0 ? k : 1; }();
+  return v;
+}
 static inline int tiles_x_of(int W) { return (W + 7) / 8; }
 static inline int tiles_y_of(int H) { return (H + 7) / 8; }
 
@@ -452,6 +458,9 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
             b[3 + q] = std::max(v[q], std::max(v[3 + q], v[6 + q])) + 1e-8;
           }
         } else if (kind == RT_PRIM_SPHERE) {
+          // a negative radius gives the reference an inside-out box (Sphere.hs:20-22: c - r > c + r) that its slab test and
+          // unions treat differently from the |r| box: such scenes keep to the reference's own tree (no fast tree)
+          if (prims[i].d[3] < 0.0) finite.store(false);
           const double r = std::fabs(prims[i].d[3]);
           for (int q = 0; q < 3; ++q) { b[q] = prims[i].d[q] - r; b[3 + q] = prims[i].d[q] + r; }
         } else {
@@ -701,7 +710,7 @@ int rt_fast_bvh_build(int32_t n_prims, const double *boxes, int32_t max_leaf, in
 int rt_tile_count(int32_t W, int32_t H, int32_t rank, int32_t world) {
   if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad tile query");
   int tx = tiles_x_of(W), ty = tiles_y_of(H), n = 0;
-  for (int y = 0; y < ty; ++y) n += tiles_in_row(tx, y, rank, world);
+  for (int y = 0; y < ty; ++y) n += tiles_in_row(tx, y, rank, world, tile_skew());
   return n;
 }
 
@@ -710,7 +719,7 @@ int rt_tile_list(int32_t W, int32_t H, int32_t rank, int32_t world, int32_t *til
   int tx = tiles_x_of(W), ty = tiles_y_of(H), n = 0;
   for (int y = 0; y < ty; ++y)
     for (int x = 0; x < tx; ++x)
-      if (((x + y) % world) == rank) tiles[n++] = y * tx + x;
+      if (((x + (long long)tile_skew() * y) % world) == rank) tiles[n++] = y * tx + x;
   return n;
 }
 
@@ -741,7 +750,7 @@ static int ensure_tiles(Workspace &ws, int W, int H, int rank, int world, hipStr
   }
   const int ty = tiles_y_of(H);
   if (n > 0) {
-    hipLaunchKernelGGL(k_make_tiles, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, stream, tiles_x_of(W), ty, rank, world, ws.tiles);
+    hipLaunchKernelGGL(k_make_tiles, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, stream, tiles_x_of(W), ty, rank, world, tile_skew(), ws.tiles);
     HIP_TRY(hipGetLastError());
   }
   ws.tl_w = W; ws.tl_h = H; ws.tl_rank = rank; ws.tl_world = world; ws.tl_n = n;
@@ -951,7 +960,7 @@ static int cached_tiles(int W, int H, int rank, int world, const int32_t **d_til
   if (hipMalloc((void **)&d, (size_t)std::max(1, cnt) * sizeof(int32_t)) != hipSuccess) return fail(RT_ERR_OOM, "tile list of %d entries", cnt);
   if (cnt > 0) {
     const int ty = tiles_y_of(H);
-    hipLaunchKernelGGL(k_make_tiles, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, stream, tiles_x_of(W), ty, rank, world, d);
+    hipLaunchKernelGGL(k_make_tiles, dim3((unsigned)((ty + 255) / 256)), dim3(256), 0, stream, tiles_x_of(W), ty, rank, world, tile_skew(), d);
     HIP_TRY(hipGetLastError());
     if (stream != nullptr) HIP_TRY(hipStreamSynchronize(stream));   // later callers may use another stream
     else HIP_TRY(hipDeviceSynchronize());

@@ -12,6 +12,7 @@ every world size.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -28,14 +29,19 @@ def tiles_y(height):
     return (height + 7) // 8
 
 
+def tile_skew() -> int:
+    """1 unless RT_TILE_SKEW says otherwise (the experiment knob librtcore reads too, tools/rank_timing.py)."""
+    return max(1, int(os.environ.get("RT_TILE_SKEW", "1") or 1))
+
+
 def tile_owner(tx, ty, world):
-    return (tx + ty) % world
+    return (tx + tile_skew() * ty) % world
 
 
 def tile_list_host(width, height, rank, world) -> np.ndarray:
     """Pure-host statement of rt_tile_list (tested equal to it): this rank's tile ids, increasing."""
     ty, tx = np.meshgrid(np.arange(tiles_y(height)), np.arange(tiles_x(width)), indexing="ij")
-    own = ((tx + ty) % world) == rank
+    own = ((tx + tile_skew() * ty) % world) == rank
     return (ty * tiles_x(width) + tx)[own].astype(np.int32)
 
 

@@ -156,3 +156,33 @@ def test_sky_loader(tmp_path):
     b = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), shape=(6,)).copy()
     F.host().rth_sky_free(px)
     assert fmt.value == F.RT_SKY_RGB8 and b.tolist() == [1, 2, 3, 4, 5, 6]
+
+
+def test_edge_inputs_follow_the_reference(tmp_path):
+    """aeson's number grammar (no hex floats / inf / nan), lazy OBJ vertices (a malformed `v` line only fails when
+    a face uses it, Object.hs:19,39-40,52-54), `read :: Int` for illum ("2.0" is no parse)."""
+    def load(cfg_text):
+        p = tmp_path / "c.json"
+        p.write_text(cfg_text)
+        h = C.c_void_p()
+        rc = F.host().rth_config_load(str(p).encode(), C.byref(h))
+        if rc == 0:
+            F.host().rth_config_destroy(h)
+        return rc
+    import json
+    good = json.dumps(base_config({}))
+    assert load(good) == 0
+    for bad_number in ("0x1p3", "-inf", "-nan", "+1", "1.", ".5", "01"):
+        assert load(good.replace('"gamma": 1.0', f'"gamma": {bad_number}')) != 0, bad_number
+    assert load(good.replace('"gamma": 1.0', '"gamma": -1.5e+2')) == 0
+    obj = tmp_path / "m.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 9 9 9 9\nv oops 1 2\nf 1 2 3\n")             # vertices 4 and 5 are malformed but unused
+    cfg = base_config({"objFiles": [{"path": str(obj), "objposition": [0, 0, 0]}]})
+    assert load(json.dumps(cfg)) == 0
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 9 9 9 9\nf 1 2 4\n")                          # ... and used
+    assert load(json.dumps(cfg)) != 0
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 0 0\nNi 1.5\nillum 2.0\n")
+    obj.write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    assert load(json.dumps(cfg)) != 0
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 0 0\nNi 1.5\nillum 7\n")
+    assert load(json.dumps(cfg)) == 0

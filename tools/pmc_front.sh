@@ -13,7 +13,9 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_render_tiles<float, false>" in r["Kernel_Name"]:
+        if "k_render_tiles<float, false" in r["Kernel_Name"]:   # the timed variants: <float, false, true|false>
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
+if not agg:
+    sys.exit("no counter row matched k_render_tiles<float, false...>: the kernel was renamed?")
 for k in sorted(agg): print(f"{k:28s} {agg[k]:.4e}")
 PY

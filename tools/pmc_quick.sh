@@ -15,8 +15,10 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(float)
 for f in glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_render_tiles<float, false>" in r["Kernel_Name"]:
+        if "k_render_tiles<float, false" in r["Kernel_Name"]:   # the timed variants: <float, false, true|false>
             agg[(f.split("/")[-2], r["Counter_Name"])] = float(r["Counter_Value"]) + agg[(f.split("/")[-2], r["Counter_Name"])]
+if not agg:
+    sys.exit("no counter row matched k_render_tiles<float, false...>: the kernel was renamed?")
 d = {k[1]: v for k, v in agg.items() if k[0] == "a"}; e = {k[1]: v for k, v in agg.items() if k[0] == "b"}
 wc = d["SQ_WAVE_CYCLES"]
 print("waves", d["SQ_WAVES"], "INSTS_VALU %.3e" % d["SQ_INSTS_VALU"], "SALU %.3e" % e["SQ_INSTS_SALU"], "VMEM_RD %.3e" % e["SQ_INSTS_VMEM_RD"], "LDS %.3e" % e["SQ_INSTS_LDS"])
