@@ -133,7 +133,11 @@ typedef struct rt_params {
   int32_t  samples_per_pixel;
   int32_t  antialiasing;      /* 0: offsets fixed at 0.5 (RenderWorker.hs:98-99)          */
   int32_t  max_bounces;
-  int32_t  rr_start_bounce;   /* 0 = off (reference behaviour; Config.hs:57). Extension: must be 0 for parity. */
+  int32_t  rr_start_bounce;   /* 0 = off: the reference's behaviour ("Russian roulette removed", Config.hs:57) and what every parity
+                                 run uses.  k > 0 (extension, BASELINE config 4): once a path has made k bounces each further bounce
+                                 survives with probability q = clamp(max channel of the attenuation, 0.05, 1); a survivor's deeper value
+                                 is weighted 1/q outside the reference's clamp, a terminated path adds nothing deeper.  Unbiased for the
+                                 reference's estimator where its clamp(., 0, 10) is inactive. */
   double   exposure;          /* toneMap,      Trace.hs:96-101  */
   double   gamma;             /* gammaCorrect, Trace.hs:103-105 (used as the exponent) */
   uint64_t seed;

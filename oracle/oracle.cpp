@@ -499,7 +499,15 @@ inline V3 backgroundSample(const Scene &s, V3 attenuation, const Ray &ray) {   /
 
 // traceLoop, Trace.hs:22-76.  `bounce` counts hits so far (selects the RNG stream that replaces
 // the threaded StdGen: the 4 draws of :38-41 come from stream 1+bounce).
-V3 traceLoop(const Scene &s, const Ray &ray0, const Ray &ray, int depth, V3 attenuation, const RngKey &key, int bounce, Counters *c) {
+//
+// rrStart > 0 is the EXTENSION BASELINE.json's config 4 names ("Russian roulette"; not in the reference: Config.hs:57
+// "Russian roulette removed"), restated here only so that the kernel's opt-in implementation has a checker; with
+// rrStart = 0 the function below is the reference's traceLoop, untouched.  Definition: once a path
+// has made rrStart bounces, each further bounce survives with probability q = clamp(max channel of the new
+// attenuation, 0.05, 1), decided by a uniform drawn from the bounce's RNG stream (sub-counter 1); a survivor's deeper
+// value is weighted 1/q OUTSIDE the reference's clamp - emitted + lit + (1/q) clamp(bounce, 0, 10) - and a terminated
+// path adds nothing deeper.  Unbiased for the reference's recursion when the clamps are inactive.
+V3 traceLoop(const Scene &s, const Ray &ray0, const Ray &ray, int depth, V3 attenuation, const RngKey &key, int bounce, Counters *c, int rrStart = 0) {
   if (depth == 0) return backgroundSample(s, attenuation, ray0);             // :22
   HitRecord rec;
   if (c) c->rays_closest++;
@@ -544,8 +552,17 @@ V3 traceLoop(const Scene &s, const Ray &ray0, const Ray &ray, int depth, V3 atte
     nextRay = {hitPoint, normalize(scatterDir)};
   }
   V3 newAttenuation = transIsOne ? attenuation : mul(attenuation, surfaceColor);   // :69-72
-  V3 bounceColor = traceLoop(s, ray0, nextRay, depth - 1, newAttenuation, key, bounce + 1, c);   // :74
+  double rrWeight = 1.0;
+  if (rrStart > 0 && bounce + 1 >= rrStart && depth - 1 > 0) {               // (extension) roulette before the next bounce is traced
+    double q = std::min(1.0, std::max(0.05, std::max(newAttenuation.x, std::max(newAttenuation.y, newAttenuation.z))));
+    uint32_t w2[4];
+    draw(key, 1u + (uint32_t)bounce, 1, w2);
+    if (!(u01(w2[0]) < q)) return add(emitted, litColor);                    // terminated: nothing deeper
+    rrWeight = 1.0 / q;
+  }
+  V3 bounceColor = traceLoop(s, ray0, nextRay, depth - 1, newAttenuation, key, bounce + 1, c, rrStart);   // :74
   V3 clamped = clampV(bounceColor, 0, 10.0);                                 // :75
+  if (rrStart > 0) clamped = scale(rrWeight, clamped);
   return add(add(emitted, litColor), clamped);                               // :76
 }
 
@@ -667,7 +684,7 @@ int orc_render(const orc_scene *o, const rt_camera *cam, const rt_params *prm,
             bool h = prm->max_bounces > 0 && hitBVH(s.bvh.get(), ray, {0.001, 10000}, r0, nullptr);
             prim_id[(size_t)j * W + i] = h ? r0.primId : -1;
           }
-          V3 col = traceLoop(s, ray, ray, prm->max_bounces, V3{1, 1, 1}, key, 0, c);   // :106, Trace.hs:20
+          V3 col = traceLoop(s, ray, ray, prm->max_bounces, V3{1, 1, 1}, key, 0, c, prm->rr_start_bounce);   // :106, Trace.hs:20
           colsum = add(colsum, col);
         }
         V3 averaged = scale(1.0 / (double)spp, colsum);                    // :114

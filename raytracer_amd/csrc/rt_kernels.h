@@ -60,6 +60,7 @@ struct KFrame {
   uint32_t n_items;            // (tile_end - tile_begin) * 64 * spp
   uint32_t chunk;              // items a wave takes from the counter at a time (a multiple of 64, set per launch)
   double *samples;             // [n_items][3] radiance of every path of this launch, summed per pixel by k_resolve
+  int32_t rr_start;            // 0: off (the reference); k > 0: Russian roulette once a path has made k bounces (opt-in extension)
   int32_t lit_row;             // first row of literal_hit's per-lane stack within a wave's fscratch block (scenes with planes), else -1
   unsigned long long *dbg;     // experiment builds (-DRT_TIMERS) only: 4 words per wave, see the end of k_render_tiles
 };

@@ -97,7 +97,7 @@
 // The per-lane path record.  Its hot rows live in LDS next to the traversal stack ([wave][row][lane], doubles);
 // the rows only spheres / planes / glass / metal use stay in global memory, followed by the stack's overflow rows.
 enum { LR_ATT = 0, LR_FA = 3, LR_FL = 6, LR_FH = 9, LR_SB = 12 /* int2: sample, bounce */, LR_ROWS = 13 };
-enum { PR_UDIR = 0, PR_NRM = 3, PR_ROWS = 6 };
+enum { PR_UDIR = 0, PR_NRM = 3, PR_S = 6 /* Russian roulette (opt-in extension): the weight of everything deeper */, PR_ROWS = 7 };
 #define HITP_FRONT ((int)0x80000000)   // lane register hitp: the primitive of the path's current hit | front-face bit
 
 RT_DEV d3 rec_ld(const double *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
@@ -164,7 +164,9 @@ __device__ __attribute__((noinline)) bool tie_candidate_wins(const int32_t *leaf
 
 // FAST: the kernel traverses the render core's own SAH tree (rt_fastbvh.h); primitives carry their index in the
 // reference's leaf order, and exact ties are settled as the reference's traversal would (tie_candidate_wins).
-template <typename BT, bool STATS, bool FAST>
+// RR: the opt-in Russian roulette extension (rt_params.rr_start_bounce > 0) is a separate instantiation, so that the kernel
+// of the reference's estimator carries none of its code (compiled in as a run-time branch it cost 4 % of the frame).
+template <typename BT, bool STATS, bool FAST, bool RR = false>
 __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles(const KScene sc, const KFrame fr) {
   extern __shared__ uint2 lds_all[];                       // [top_nodes] cached nodes (64 B each), then per wave: RT_STACK_LDS stack rows + LR_ROWS record rows
   const int lane = threadIdx.x & 63;
@@ -256,7 +258,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)sb.x, o_, bgdir);
       }
       const d3 att = rec_ld(lrec, LR_ATT), fa = rec_ld(lrec, LR_FA), fl = rec_ld(lrec, LR_FL), fh = rec_ld(lrec, LR_FH);
-      const d3 T = att * background(sc, bgdir);
+      d3 T = att * background(sc, bgdir);
+      if (RR) T = rec[PR_S * 64] * T;       // (extension) the roulette weight of this depth
       const d3 R = clamp3(T + fa, fl, fh);
       double *o_ = fr.samples + 3 * (size_t)item;
       o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             rec_st(lrec, LR_ATT, mk3(1, 1, 1)); rec_st(lrec, LR_FA, mk3(0, 0, 0));
             rec_st(lrec, LR_FL, mk3(-inf, -inf, -inf)); rec_st(lrec, LR_FH, mk3(inf, inf, inf));
             rec_sti(lrec, LR_SB, (int)smp, 0);
+            if (RR) rec[PR_S * 64] = 1.0;
             li = -1;
             RT_BEGIN_QUERY(RT_TMAX);
           } else {
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             if (M.flags & (DMAT_GLASS_DIR | DMAT_METAL))    // unitDir (Trace.hs:32) is only used by the glass and metal bounces
               rec_st(r, PR_UDIR, normalize3(rd));
             hitp = best | (front ? HITP_FRONT : 0);
-            fa = fa + ld3(M.emission);                       // emitted (Trace.hs:29) joins the pending offset
+            if (RR) fa = fa + r[PR_S * 64] * ld3(M.emission);   // (extension) weighted by the roulette survivals so far
+            else fa = fa + ld3(M.emission);                  // emitted (Trace.hs:29) joins the pending offset
             rec_st(lrec, LR_FA, fa);
             ro = hp;                                         // shadow rays and the bounce ray start at the un-offset hit point
             if (STATS) st[STAT_SHADED]++;
@@ -463,7 +468,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             } else {
               contrib = lightPower * ld3(L.intensity);
             }
-            fa = fa + ld3(M.diffuse) * contrib;              // litColor = surfaceColor * directLight (Trace.hs:36), light by light
+            if (RR) fa = fa + r[PR_S * 64] * (ld3(M.diffuse) * contrib);
+            else fa = fa + ld3(M.diffuse) * contrib;         // litColor = surfaceColor * directLight (Trace.hs:36), light by light
             rec_st(lrec, LR_FA, fa);
           }
           --li;
@@ -499,10 +505,28 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         if (need_scatter) {                                  // Trace.hs:27-76
           RT_COLD_ARGS();
           const bool front = (hitp & HITP_FRONT) != 0;
+          if (RR && !(M.flags & DMAT_NO_ATTEN)) { att = att * ld3(M.diffuse); rec_st(lrec, LR_ATT, att); }   // (the roulette needs the new attenuation first)
+          // (extension, off unless rt_params.rr_start_bounce > 0) Russian roulette before the next bounce is traced: survive with
+          // probability q = clamp(max channel of the new attenuation, 0.05, 1); a survivor's deeper value is weighted 1/q outside
+          // the clamp, a terminated path adds nothing deeper: F(x) = clamp(s x + a, L, H) with s the product of the weights so far
+          double ten = 10.0;
+          bool rr_dead = false;
+          if (RR) {
+            double sw = r[PR_S * 64];
+            const int nb = sb.y + 1;
+            if (nb >= fr.rr_start && nb < fr.maxb) {
+              const double q = fmin(1.0, fmax(0.05, fmax(att.x, fmax(att.y, att.z))));
+              const u4 w2 = philox4x32_10(pixel, (uint32_t)sb.x, 1u + (uint32_t)sb.y, 1u, fr.key0, fr.key1);
+              rr_dead = !(u01(w2.x) < q);
+              sw = sw * (1.0 / q);
+            }
+            if (rr_dead) { att = mk3(0, 0, 0); rec_st(lrec, LR_ATT, att); }      // the sample is F(0): finished below without a fold
+            else { r[PR_S * 64] = sw; ten = 10.0 * sw; }
+          }
           // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
           //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)
-          {
-            const d3 nl = clamp3(fa, fl, fh), nh = clamp3(mk3(fa.x + 10.0, fa.y + 10.0, fa.z + 10.0), fl, fh);
+          if (!rr_dead) {
+            const d3 nl = clamp3(fa, fl, fh), nh = clamp3(mk3(fa.x + ten, fa.y + ten, fa.z + ten), fl, fh);
             fl = nl; fh = nh;
             rec_st(lrec, LR_FL, fl);
             rec_st(lrec, LR_FH, fh);
@@ -526,11 +550,12 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           } else {                                                               // :65-67
             rd = normalize3(nrm + randVec);
           }
-          if (!(M.flags & DMAT_NO_ATTEN)) { att = att * ld3(M.diffuse); rec_st(lrec, LR_ATT, att); }   // :69-72
+          if (!RR && !(M.flags & DMAT_NO_ATTEN)) { att = att * ld3(M.diffuse); rec_st(lrec, LR_ATT, att); }   // :69-72
           sb.y += 1;
           rec_sti(lrec, LR_SB, sb.x, sb.y);
           li = -1;
           if (sb.y >= fr.maxb) { need_ray0 = true; need_finish = true; }         // depth 0: background along ray0, :22
+          if (rr_dead) need_finish = true;                                       // (extension) att = 0: the sample is clamp(a, L, H)
         }
         RT_MARK("SH_SCATTER_END");
         RT_TICK_SH(9);

@@ -730,7 +730,7 @@ static int check_frame(const rt_scene *s, const rt_camera *cam, const rt_params 
   if (p->width <= 0 || p->height <= 0 || p->samples_per_pixel <= 0 || p->max_bounces < 0)
     return fail(RT_ERR_INVALID, "bad image/raytracer settings");
   if ((long long)p->width * p->height >= (1LL << 31)) return fail(RT_ERR_UNSUPPORTED, "image too large");
-  if (p->rr_start_bounce != 0) return fail(RT_ERR_UNSUPPORTED, "Russian roulette is not in the reference (Config.hs:57) and not implemented");
+  if (p->rr_start_bounce < 0) return fail(RT_ERR_INVALID, "rr_start_bounce must be >= 0 (0 = off, the reference's behaviour)");
   if (p->box_precision < 0 || p->box_precision > 2) return fail(RT_ERR_INVALID, "box_precision must be 0, 1 or 2");
   return RT_OK;
 }
@@ -760,7 +760,7 @@ static int ensure_tiles(Workspace &ws, int W, int H, int rank, int world, hipStr
 // One frame (or one rank's share of it) = one or more launches of k_render_tiles + k_resolve.  A launch covers a
 // range of the rank's tiles whose per-path radiance fits the sample buffer; normally that is the whole frame
 // (1080p x 100 spp: 5 GB of 288 GB).  The split never changes a result: k_resolve sums in sample order.
-template <typename BT, bool STATS, bool FAST>
+template <typename BT, bool STATS, bool FAST, bool RR = false>
 static int launch_kernel(Replica *s, Workspace &ws, const KFrame &fr_in, hipStream_t stream) {
   KFrame fr = fr_in;
   const DevCtx &dc = g_dev[s->device];
@@ -793,7 +793,7 @@ static int launch_kernel(Replica *s, Workspace &ws, const KFrame &fr_in, hipStre
   size_t lds = lds_waves + (size_t)fr.top_nodes * sizeof(DNode<float>);
   if (const char *pad = getenv("RT_LDS_BYTES")) lds = std::max(lds, (size_t)atol(pad));   // experiment knob: caps blocks per CU
   if (lds > lds_cu) return fail(RT_ERR_UNSUPPORTED, "traversal stack needs %zu bytes of LDS", lds);
-  auto kern = k_render_tiles<BT, STATS, FAST>;
+  auto kern = k_render_tiles<BT, STATS, FAST, RR>;
   if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
@@ -906,6 +906,7 @@ static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const 
   fr.cam = *cam;
   fr.W = p->width; fr.H = p->height; fr.spp = p->samples_per_pixel; fr.aa = p->antialiasing != 0; fr.maxb = p->max_bounces;
   fr.exposure = p->exposure; fr.gamma = p->gamma;
+  fr.rr_start = p->rr_start_bounce;
   fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
   fr.tiles_x = tiles_x_of(p->width);
   if (world > 1) {
@@ -923,6 +924,11 @@ static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const 
 #else
   const bool st = p->collect_stats != 0;
 #endif
+  if (fr.rr_start > 0) {                                    // the opt-in extension has its own instantiations
+    if (p->box_precision == 1) return st ? launch_kernel<double, true, false, true>(s, ws, fr, stream) : launch_kernel<double, false, false, true>(s, ws, fr, stream);
+    if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true, true>(s, ws, fr, stream);
+    return st ? launch_kernel<float, true, false, true>(s, ws, fr, stream) : launch_kernel<float, false, false, true>(s, ws, fr, stream);
+  }
   if (p->box_precision == 1) return st ? launch_kernel<double, true, false>(s, ws, fr, stream) : launch_kernel<double, false, false>(s, ws, fr, stream);
   if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true>(s, ws, fr, stream);
   return st ? launch_kernel<float, true, false>(s, ws, fr, stream) : launch_kernel<float, false, false>(s, ws, fr, stream);

@@ -191,8 +191,8 @@ def test_error_paths(need_gpu):
     spec = scenes.c2_spheres(width=64, height=32, spp=1)
     g = api.GpuScene(spec)
     with pytest.raises(F.RtError) as e:
-        g.render(rr_start_bounce=2)
-    assert e.value.code == F.RT_ERR_UNSUPPORTED
+        g.render(rr_start_bounce=-1)
+    assert e.value.code == F.RT_ERR_INVALID
     with pytest.raises(F.RtError):
         g.render(width=0)
     g.close()
