@@ -53,6 +53,16 @@ int main(int argc, char **argv) {
   }
   printf("[Scene Setup] Sky sphere loaded.\n");
   printf("[Scene Setup] Camera created, lights are set up.\n");
+  // RT_DEVICES: the device group of the single blocking rt_render below, as the Haskell binding selects it
+  // (integration/Rendering/GpuRender.hs: rt_init_devices 0 NULL = every visible GPU).  "all" or a comma-separated id list
+  // (ids may repeat: virtual devices on one GPU); unset = the current device only.
+  if (const char *devs = getenv("RT_DEVICES")) {
+    std::vector<int32_t> ids;
+    if (strcmp(devs, "all") != 0)
+      for (const char *q = devs; *q;) { ids.push_back((int32_t)strtol(q, (char **)&q, 10)); if (*q == ',') ++q; else if (*q) break; }
+    if (rt_init_devices((int32_t)ids.size(), ids.empty() ? nullptr : ids.data()) != RT_OK) { fprintf(stderr, "rtcore: %s\n", rt_last_error()); return 1; }
+    printf("[Rendering] device group of %d\n", rt_device_count());
+  }
   rt_scene *scene = nullptr;
   if (rt_scene_create(&desc, &scene) != RT_OK) { fprintf(stderr, "rtcore: %s\n", rt_last_error()); return 1; }
   printf("[Rendering] Launching the MI355X render core...\n");
