@@ -65,8 +65,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: take the RCCL code path (process group, all-reduce, gather of device tensors, barrier) even with
+    # one rank - the one-GPU test box's rehearsal of what the 8-GPU run executes (tests/test_gpu_dist.py)
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     mk = {"c4": scenes.c4_shipped, "c4v": scenes.c4_blob63k, "c3": scenes.c3_blob988, "c2": scenes.c2_spheres, "c5": scenes.c5_multi}[args.workload]
@@ -81,7 +85,7 @@ def main():
     packed = torch.zeros((n_max * 64, 3), dtype=torch.float64, device=dev)
     packed8 = torch.zeros((n_max * 64, 3), dtype=torch.uint8, device=dev)      # the rank's tiles as the 8-bit frame: what is gathered
     rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=dev) if rank == 0 else None
-    bufs = [torch.empty_like(packed8) for _ in range(world)] if (rank == 0 and world > 1) else None
+    bufs = [torch.empty_like(packed8) for _ in range(world)] if (rank == 0 and use_dist) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     # ---- untimed counting passes: rays / nodes / primitive tests of this rank's share (deterministic per seed).
@@ -101,7 +105,7 @@ def main():
     cnt = torch.tensor([st.rays_closest, st.rays_shadow, st.nodes_visited, st.tri_tests, st.sphere_tests, st.plane_tests,
                         st.shaded_hits, st.paths, st.rays_shadow_culled], dtype=torch.int64, device=dev)
     my_cnt = cnt.clone()
-    if world > 1:
+    if use_dist:
         dist.all_reduce(cnt)
     tot = [int(x) for x in cnt.tolist()]
     rays_total = tot[0] + tot[1]
@@ -117,20 +121,20 @@ def main():
         # showPixel's quantisation (RenderWorker.hs:108-109) is per value, so it is applied to the rank's packed tiles and
         # the 8-bit frame is what crosses xGMI: 3 bytes per pixel instead of 24
         F.check(F.core().rt_quantize_device(C.c_void_p(packed.data_ptr()), C.c_void_p(packed8.data_ptr()), packed.numel(), C.c_void_p(stream)))
-        rdist.gather_frame(packed8, W, H, rank, world, image=rgb8, gather_buffers=bufs)
+        rdist.gather_frame(packed8, W, H, rank, world, image=rgb8, gather_buffers=bufs, force_collective=use_dist)
 
     from raytracer_amd import _ffi as F
     for _ in range(args.warmup):
         step()
     scene.kernel_times()                                             # discard the launches so far
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -139,7 +143,7 @@ def main():
     kernel_ms = k_sum / max(1, k_n)
 
     tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
     ms_per_step = elapsed / args.steps * 1e3
@@ -231,7 +235,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, args.cpu_threads)
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

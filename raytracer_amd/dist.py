@@ -75,11 +75,11 @@ def untile_into(image: torch.Tensor, packed: torch.Tensor, width, height, rank, 
 
 
 def gather_frame(packed: torch.Tensor, width, height, rank, world, image: torch.Tensor | None = None,
-                 gather_buffers: list | None = None):
+                 gather_buffers: list | None = None, force_collective: bool = False):
     """The exchange step.  packed: (max_tiles*64, C) on every rank (padded to the largest tile count so
     the gather is regular).  Returns the (H, W, C) frame on rank 0, None elsewhere."""
     n_comp = packed.shape[-1]
-    if world == 1:
+    if world == 1 and not force_collective:      # (force_collective: the one-rank rehearsal of the collective path)
         if image is None:
             image = torch.empty((height, width, n_comp), dtype=packed.dtype, device=packed.device)
         return untile_into(image, packed, width, height, 0, 1)

@@ -47,3 +47,28 @@ def test_two_processes_one_frame(need_gpu, tmp_path):
     mp.spawn(worker, args=(2, port, out), nprocs=2, join=True)
     both = np.load(out)
     assert np.array_equal(both[0], both[1])
+
+
+@pytest.mark.timeout(300)
+def test_bench_rccl_code_path_with_one_rank(need_gpu):
+    """bench.py's RCCL branch (backend "nccl": process group bound to the device, all-reduce of the counters, barrier, gather of
+    the packed 8-bit tiles as device tensors, un-tiling) cannot run with two ranks on one GPU, and no 8-GPU node was available to
+    the driver in round 1 - so it is rehearsed with ONE rank under torch.distributed.run, exactly as the driver launches it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "180", "--spp", "4", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["kernel_ms"] > 0
