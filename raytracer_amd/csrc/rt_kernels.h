@@ -312,21 +312,26 @@ RT_DEV bool box_interval(const BoxRay<double> &r, const double *bx, double tmin,
 #define PLANE_MISS 0
 #define PLANE_HIT 1
 #define PLANE_LITERAL 2
+// A hit at distance t of a primitive that its own box does NOT contain (a plane; a sphere of negative radius, whose box
+// c -+ r is inside out, Sphere.hs:20-22), classified against the interval its leaf receives.  bi: index of the leaf's FP64
+// box in plane_boxes, < 0 for a single-leaf root (the raw ray interval, BVH.hs:121, Trace.hs:24).
+RT_DEV int classify_in_leaf(long long bi, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double t) {
+  if (bi < 0) return (t >= tmin && t <= tmax) ? PLANE_HIT : PLANE_MISS;
+  BoxRay<double> br;
+  make_boxray(br, ro, rd, 0.0f);
+  double te, tx;
+  if (!box_interval(br, plane_boxes + 6 * bi, tmin, tmax, te, tx)) return PLANE_MISS;   // the leaf is not entered (or only behind a closer hit)
+  if (!(t >= te && t <= tmax)) return PLANE_MISS;              // `contains interval t` (tmax = the closest hit so far)
+  (void)box_interval(br, plane_boxes + 6 * bi, tmin, __builtin_huge_val(), te, tx);     // the box's own exit
+  return t <= tx ? PLANE_HIT : PLANE_LITERAL;
+}
 RT_DEV int hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double &tout) {
   d3 pp = mk3(P.d[0], P.d[1], P.d[2]), n = mk3(P.d[3], P.d[4], P.d[5]);
   double denom = dot3(rd, n);                                  // Plane.hs:22
   if (!(fabs(denom) > 1e-6)) return PLANE_MISS;                // :23
   double t = dot3(pp - ro, n) / denom;                         // :25
   tout = t;
-  long long bi = (long long)P.d[6];
-  if (bi < 0) return (t >= tmin && t <= tmax) ? PLANE_HIT : PLANE_MISS;   // single-leaf root: the raw ray interval (BVH.hs:121, Trace.hs:24)
-  BoxRay<double> br;
-  make_boxray(br, ro, rd, 0.0f);
-  double te, tx;
-  if (!box_interval(br, plane_boxes + 6 * bi, tmin, tmax, te, tx)) return PLANE_MISS;   // the leaf is not entered (or only behind a closer hit)
-  if (!(t >= te && t <= tmax)) return PLANE_MISS;              // :26 (tmax = the closest hit so far)
-  (void)box_interval(br, plane_boxes + 6 * bi, tmin, __builtin_huge_val(), te, tx);     // the box's own exit
-  return t <= tx ? PLANE_HIT : PLANE_LITERAL;
+  return classify_in_leaf((long long)P.d[6], plane_boxes, ro, rd, tmin, tmax, t);      // :26
 }
 
 // The reference's `hit` on its own tree (BVH.hs:120-143) walked LITERALLY for one ray: FP64 boxes, every child entered

@@ -663,11 +663,19 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           // instructions) in front of the branch and every triangle test pays for it.
           d3 ro_ = ro, rd_ = rd;
           asm volatile("" : "+v"(ro_.x), "+v"(ro_.y), "+v"(ro_.z), "+v"(rd_.x), "+v"(rd_.y), "+v"(rd_.z));
-          if (isl && kind == RT_PRIM_SPHERE) { if (STATS) st[STAT_SPHERE]++; h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t); }
-          else if (isl && kind == RT_PRIM_PLANE) {
+          int ps = PLANE_MISS;
+          if (isl && kind == RT_PRIM_SPHERE) {
+            if (STATS) st[STAT_SPHERE]++;
+            h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t);
+            // a sphere of negative radius lies outside its own (inside-out) box: like a plane, it is seen only through the
+            // interval its leaf receives
+            if (h && P.d[3] < 0.0) { ps = classify_in_leaf((long long)P.d[6], sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t); h = ps == PLANE_HIT; }
+          } else if (isl && kind == RT_PRIM_PLANE) {
             if (STATS) st[STAT_PLANE]++;
-            const int ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);
+            ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);
             h = ps == PLANE_HIT;
+          }
+          {
             if (ps == PLANE_LITERAL) {
               // The plane is crossed beyond its leaf box's exit: the reference sees it only if that leaf is visited second
               // and its sibling produced a hit (BVH.hs:137-138) - a property of the reference's traversal, so the whole

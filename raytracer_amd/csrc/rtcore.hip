@@ -159,6 +159,7 @@ struct HostScene {
   const void *sky = nullptr;
   size_t sky_bytes = 0;
   bool has_fast = false;
+  bool inverted_boxes = false;          // a sphere of negative radius: only the exact FP64 slab test reproduces the reference
   int n_internal = 0, depth = 0, f_internal = 0, f_depth = 0, f_root_ref = 0;
   KScene ks{};                          // the non-pointer fields
 };
@@ -186,6 +187,7 @@ struct Replica {
   KScene ks{};
   int n_internal = 0, depth = 0;
   bool has_boxed_planes = false;        // some plane sits in a non-root leaf: its visibility can depend on the reference's traversal (literal_hit)
+  bool inverted_boxes = false;          // every box_precision runs the exact FP64 path
   Workspace ws;                         // owned, growable
   // cached outputs of rt_render: full frame (single device, or device 0 of a group) ...
   size_t cap_px = 0;
@@ -391,7 +393,9 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
     for (long k = first; k < first + cnt; ++k) {
       if (in_leaf[k]) { return fail(RT_ERR_INVALID, "primitive %ld belongs to two leaves", k); }
       in_leaf[k] = 1;
-      if ((prims[k].kind & DPRIM_KIND_MASK) == RT_PRIM_PLANE && i != 0) {   // the root's own box is never tested (BVH.hs:123)
+      const uint32_t kd = prims[k].kind & DPRIM_KIND_MASK;
+      if (kd == RT_PRIM_SPHERE) prims[k].d[6] = -1.0;                      // (only read for a negative radius)
+      if ((kd == RT_PRIM_PLANE || (kd == RT_PRIM_SPHERE && prims[k].d[3] < 0.0)) && i != 0) {   // primitives their own box does not contain; the root's own box is never tested (BVH.hs:123)
         prims[k].d[6] = (double)(plane_boxes.size() / 6);
         for (int q = 0; q < 6; ++q) plane_boxes.push_back(d->node_bounds[6 * (size_t)i + q]);
       }
@@ -446,7 +450,7 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
   bool fast_ok = !is_leaf(0);
   if (fast_ok) {
     std::vector<double> pbox((size_t)np * 6);
-    std::atomic<bool> finite(true);
+    std::atomic<bool> finite(true), inverted(false);
     parallel_for((size_t)np, n_host_threads, [&](size_t i0, size_t i1) {
       for (size_t i = i0; i < i1; ++i) {
         double *b = &pbox[6 * i];
@@ -459,8 +463,9 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
           }
         } else if (kind == RT_PRIM_SPHERE) {
           // a negative radius gives the reference an inside-out box (Sphere.hs:20-22: c - r > c + r) that its slab test and
-          // unions treat differently from the |r| box: such scenes keep to the reference's own tree (no fast tree)
-          if (prims[i].d[3] < 0.0) finite.store(false);
+          // unions treat in their own way: such scenes keep to the reference's own tree and its exact FP64 slab test
+          // (the outward rounding and the origin margin of the FP32 boxes assume lo <= hi)
+          if (prims[i].d[3] < 0.0) { finite.store(false); inverted.store(true); }
           const double r = std::fabs(prims[i].d[3]);
           for (int q = 0; q < 3; ++q) { b[q] = prims[i].d[q] - r; b[3 + q] = prims[i].d[q] + r; }
         } else {
@@ -471,6 +476,7 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
       }
     });
     fast_ok = finite.load();
+    hs.inverted_boxes = inverted.load();
     if (fast_ok) {
       const int nt = n_host_threads;
       int max_leaf = 4;
@@ -575,6 +581,7 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
   s->depth = hs.depth; s->n_internal = hs.n_internal;
   s->has_fast = hs.has_fast; s->f_internal = hs.f_internal; s->f_depth = hs.f_depth; s->f_root_ref = hs.f_root_ref;
   s->has_boxed_planes = !hs.plane_boxes.empty();
+  s->inverted_boxes = hs.inverted_boxes;
 #define UP(call) do { if ((rc = (call))) { replica_destroy(s); return rc; } } while (0)
   UP(dev_upload(&s->d_nodes32, hs.n32.data(), hs.n32.size()));
   UP(dev_upload(&s->d_nodes64, hs.n64.data(), hs.n64.size()));
@@ -924,13 +931,14 @@ static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const 
 #else
   const bool st = p->collect_stats != 0;
 #endif
+  const int mode = s->inverted_boxes ? 1 : p->box_precision;
   if (fr.rr_start > 0) {                                    // the opt-in extension has its own instantiations
-    if (p->box_precision == 1) return st ? launch_kernel<double, true, false, true>(s, ws, fr, stream) : launch_kernel<double, false, false, true>(s, ws, fr, stream);
-    if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true, true>(s, ws, fr, stream);
+    if (mode == 1) return st ? launch_kernel<double, true, false, true>(s, ws, fr, stream) : launch_kernel<double, false, false, true>(s, ws, fr, stream);
+    if (mode == 0 && s->has_fast) return st ? launch_kernel<float, true, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true, true>(s, ws, fr, stream);
     return st ? launch_kernel<float, true, false, true>(s, ws, fr, stream) : launch_kernel<float, false, false, true>(s, ws, fr, stream);
   }
-  if (p->box_precision == 1) return st ? launch_kernel<double, true, false>(s, ws, fr, stream) : launch_kernel<double, false, false>(s, ws, fr, stream);
-  if (p->box_precision == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true>(s, ws, fr, stream);
+  if (mode == 1) return st ? launch_kernel<double, true, false>(s, ws, fr, stream) : launch_kernel<double, false, false>(s, ws, fr, stream);
+  if (mode == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true>(s, ws, fr, stream);
   return st ? launch_kernel<float, true, false>(s, ws, fr, stream) : launch_kernel<float, false, false>(s, ws, fr, stream);
 }
 
