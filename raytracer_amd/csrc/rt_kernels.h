@@ -312,9 +312,10 @@ RT_DEV bool box_interval(const BoxRay<double> &r, const double *bx, double tmin,
 #define PLANE_MISS 0
 #define PLANE_HIT 1
 #define PLANE_LITERAL 2
-// A hit at distance t of a primitive that its own box does NOT contain (a plane; a sphere of negative radius, whose box
-// c -+ r is inside out, Sphere.hs:20-22), classified against the interval its leaf receives.  bi: index of the leaf's FP64
-// box in plane_boxes, < 0 for a single-leaf root (the raw ray interval, BVH.hs:121, Trace.hs:24).
+// A hit at distance t of a plane - a primitive that its own box does NOT contain - classified against the interval its
+// leaf receives.  bi: index of the leaf's FP64 box in plane_boxes, < 0 for a single-leaf root (the raw ray interval,
+// BVH.hs:121, Trace.hs:24).  (The leaf's box is a proper box inside all its ancestors' boxes, so their clipping adds nothing;
+// spheres of radius <= 0, for which that does not hold, go to literal_hit on every candidate hit: see the PRIM step.)
 RT_DEV int classify_in_leaf(long long bi, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double t) {
   if (bi < 0) return (t >= tmin && t <= tmax) ? PLANE_HIT : PLANE_MISS;
   BoxRay<double> br;
@@ -338,7 +339,8 @@ RT_DEV int hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, do
 // with its clipped interval, the second child with [minVal iSecond, t firstHit] when the first one produced a hit
 // (:137-138), every primitive tested against the interval its leaf received (Triangle.hs:53, Sphere.hs:26, Plane.hs:26).
 // Out of line, per lane, slow, and rare: it runs only for the queries hit_plane reports as PLANE_LITERAL - a plane placed
-// outside its constant slab box (Plane.hs:20), where the reference's answer is a property of ITS traversal.
+// outside its constant slab box (Plane.hs:20), where the reference's answer is a property of ITS traversal - and for
+// candidate hits on spheres of radius <= 0 (inside-out or point-sized boxes).
 // `stk`: this lane's column of 3 * (tree depth) rows of 64 doubles in global memory (ref, lo, hi of the pending second children).
 struct LitHit { double t; int best; };
 __device__ __attribute__((noinline)) LitHit literal_hit(const DNode<double> *nodes, const DPrim *prims, int root_ref, double *stk,

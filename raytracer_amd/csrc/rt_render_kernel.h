@@ -667,9 +667,12 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if (isl && kind == RT_PRIM_SPHERE) {
             if (STATS) st[STAT_SPHERE]++;
             h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t);
-            // a sphere of negative radius lies outside its own (inside-out) box: like a plane, it is seen only through the
-            // interval its leaf receives
-            if (h && P.d[3] < 0.0) { ps = classify_in_leaf((long long)P.d[6], sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t); h = ps == PLANE_HIT; }
+            // A sphere of negative radius lies outside its own (inside-out) box c -+ r (Sphere.hs:20-22), and that box is not
+            // inside its ancestors' boxes either (a union by min / max does not contain the hull of an inside-out box); a
+            // sphere of radius 0 is a point on the faces of its own box, where every hit is rounding noise.  Both are seen only
+            // through the interval the reference's traversal hands their leaf (the chain of clipped ancestor intervals), so
+            // a candidate hit settles the whole query with the literal walk.  d[6] < 0: the leaf is the root (raw interval).
+            if (h && !(P.d[3] > 0.0) && P.d[6] >= 0.0) { ps = PLANE_LITERAL; h = false; }
           } else if (isl && kind == RT_PRIM_PLANE) {
             if (STATS) st[STAT_PLANE]++;
             ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);
@@ -690,11 +693,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           }
         }
         h = h && isl;
-        if constexpr (FAST) {                                // this tree's order is not the reference's: settle exact ties its way
+        // FAST: this tree's order is not the reference's.  FP32 boxes on the reference's tree: two children's entry distances
+        // can compare differently after rounding, so the visiting order is not always the reference's either.  Both settle
+        // exact ties (duplicated objects) the reference's way; the FP64 boxes visit in its order and need no rule.
+        if constexpr (FAST || sizeof(BT) == 4) {
           const bool tie = h && li < 0 && best >= 0 && t == best_t;
           if (__ballot(tie) != 0ull) {
             if (tie) h = tie_candidate_wins(sc.leaf_anc, sc.ref_anc, sc.ref_depth, (const DNode<double> *)sc.ref_nodes64,
-                                            ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, P.mat, best);
+                                            ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, FAST ? (int)P.mat : pi, best);
           }
         }
         best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties

@@ -394,8 +394,8 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
       if (in_leaf[k]) { return fail(RT_ERR_INVALID, "primitive %ld belongs to two leaves", k); }
       in_leaf[k] = 1;
       const uint32_t kd = prims[k].kind & DPRIM_KIND_MASK;
-      if (kd == RT_PRIM_SPHERE) prims[k].d[6] = -1.0;                      // (only read for a negative radius)
-      if ((kd == RT_PRIM_PLANE || (kd == RT_PRIM_SPHERE && prims[k].d[3] < 0.0)) && i != 0) {   // primitives their own box does not contain; the root's own box is never tested (BVH.hs:123)
+      if (kd == RT_PRIM_SPHERE) prims[k].d[6] = -1.0;                      // (only read for a radius <= 0)
+      if ((kd == RT_PRIM_PLANE || (kd == RT_PRIM_SPHERE && !(prims[k].d[3] > 0.0))) && i != 0) {   // primitives their own box does not contain; the root's own box is never tested (BVH.hs:123)
         prims[k].d[6] = (double)(plane_boxes.size() / 6);
         for (int q = 0; q < 6; ++q) plane_boxes.push_back(d->node_bounds[6 * (size_t)i + q]);
       }
@@ -588,10 +588,10 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
   if (hs.has_fast) {
     UP(dev_upload(&s->d_fnodes32, hs.fn32.data(), hs.fn32.size()));
     UP(dev_upload(&s->d_fprims, hs.fprims.data(), hs.fprims.size()));
-    UP(dev_upload(&s->d_ref_anc, hs.ref_anc.data(), hs.ref_anc.size()));
-    UP(dev_upload(&s->d_ref_depth, hs.ref_depth.data(), hs.ref_depth.size()));
-    UP(dev_upload(&s->d_leaf_anc, hs.leaf_anc.data(), hs.leaf_anc.size()));
   }
+  UP(dev_upload(&s->d_ref_anc, hs.ref_anc.data(), hs.ref_anc.size()));       // the tie rule: box_precision 0 and 2
+  UP(dev_upload(&s->d_ref_depth, hs.ref_depth.data(), hs.ref_depth.size()));
+  UP(dev_upload(&s->d_leaf_anc, hs.leaf_anc.data(), hs.leaf_anc.size()));
   UP(dev_upload(&s->d_prims, hs.prims.data(), hs.prims.size()));
   UP(dev_upload(&s->d_prim_ids, hs.pids.data(), hs.pids.size()));
   UP(dev_upload(&s->d_mats, hs.mats.data(), hs.mats.size()));

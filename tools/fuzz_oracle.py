@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Parity hunt: random scenes against the CPU ORACLE (not only mode 0 against mode 1): triangle soups with room-sized
+triangles, spheres (a few with negative or zero radius), planes of random point and normal, duplicated config triangles,
+glass / metal / emissive materials, point and directional lights, gradient / solid / LDR / HDR sky, thin lens, random
+leafThreshold / bvhMaxDepth / maxBounces, Russian roulette on some seeds; all three box_precision modes.
+Prints one line per seed; exit status 1 if any pixel's id differs or any radiance differs by more than 1e-12 (relative to
+max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as O                     # noqa: E402
+from raytracer_amd import api, scenes              # noqa: E402
+
+
+def scene(seed):
+    rng = np.random.default_rng(seed)
+    n_tris = int(rng.choice([30, 300, 3000]))
+    ctr = rng.uniform([-4, -0.5, -4], [4, 4, 4], size=(n_tris, 3))
+    size = np.where(rng.random(n_tris) < 0.02, 6.0, rng.uniform(0.05, 0.7, n_tris))
+    tri = ctr[:, None, :] + rng.uniform(-1, 1, size=(n_tris, 3, 3)) * size[:, None, None]
+    names = ["matte", "metal", "glass", "lamp", None]
+    fm = [names[i] for i in rng.integers(0, len(names), n_tris)]
+    mats = [("matte", {"diffuseColor": list(rng.uniform(0.2, 0.9, 3))}),
+            ("metal", {"diffuseColor": [0.9, 0.9, 0.9], "shininess": float(rng.choice([50.0, 300.0]))}),
+            ("glass", {"diffuseColor": [1.0, 1.0, 1.0], "ior": float(rng.uniform(1.1, 1.8)), "transmission": 1.0}),
+            ("lamp", {"diffuseColor": [0.8, 0.8, 0.8], "emissionColor": list(rng.uniform(0.0, 3.0, 3))})]
+    cfg = []
+    for _ in range(int(rng.integers(0, 7))):
+        r = float(rng.uniform(0.2, 1.3))
+        if rng.random() < 0.15:
+            r = -r
+        if rng.random() < 0.05:
+            r = 0.0
+        cfg.append(("sphere", list(rng.uniform(-3, 3, 3) + [0, 1.5, 0]), r, names[int(rng.integers(0, 5))]))
+    for _ in range(int(rng.integers(0, 4))):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        cfg.append(("plane", list(rng.uniform([-2, -1.5, -2], [2, 1.0, 2])), list(n), names[int(rng.integers(0, 5))]))
+    for _ in range(int(rng.integers(0, 3))):
+        v = rng.uniform(-5, 5, size=(3, 3))
+        cfg.append(("triangle", list(v[0]), list(v[1]), list(v[2]), names[int(rng.integers(0, 5))]))
+    lights = []
+    for _ in range(int(rng.integers(0, 4))):
+        if rng.random() < 0.6:
+            lights.append({"tag": "PointLight", "position": list(rng.uniform(-8, 8, 3) + [0, 6, 0]), "intensity": list(rng.uniform(5, 60, 3))})
+        else:
+            lights.append({"tag": "DirectionalLight", "direction": list(rng.normal(size=3)), "intensity": list(rng.uniform(0.1, 0.8, 3))})
+    bg = ({"tag": "Gradient", "color1": [1.0, 1.0, 1.0], "color2": [0.5, 0.7, 1.0]} if rng.random() < 0.5
+          else {"tag": "SolidColor", "color": list(rng.uniform(0, 1.5, 3))})
+    spec = scenes.SceneSpec(
+        name=f"fz{seed}", width=int(rng.integers(40, 160)), height=int(rng.integers(24, 90)), spp=int(rng.integers(1, 5)),
+        antialiasing=bool(rng.random() < 0.8), gamma=float(rng.choice([1.0, 0.8, 2.2])), exposure=float(rng.uniform(0.5, 2.0)),
+        background=bg,
+        camera={"lookFrom": list(rng.uniform(-9, 9, 3) + [0, 3, 0]), "lookAt": [0.0, 1.0, 0.0], "vUp": [0.0, 1.0, 0.0],
+                "vfov": float(rng.uniform(30, 90)), "aperture": float(rng.choice([0.0, 0.0, 0.3])), "focusDist": 3.0},
+        max_bounces=int(rng.integers(0, 8)), bvh_max_depth=int(rng.choice([0, 2, 6, 12, 32])), leaf_threshold=int(rng.integers(1, 9)),
+        materials=mats, lights=lights, config_objects=cfg,
+        obj_meshes=[scenes.ObjMesh(tri.reshape(-1, 3), np.arange(3 * n_tris).reshape(n_tris, 3), fm, tuple(rng.uniform(-1, 1, 3)))],
+        seed=int(rng.integers(0, 2 ** 40)))
+    k = rng.random()
+    if k < 0.25:
+        spec.sky = scenes.sky_gradient_texture(fmt="rgbf")
+    elif k < 0.4:
+        spec.sky = scenes.sky_gradient_texture(fmt="rgb8")
+    elif k < 0.5:
+        spec.sky = scenes.sunset_sky(int(rng.integers(16, 300)), int(rng.integers(8, 150)), seed=seed)
+    rr = int(rng.choice([0, 0, 0, 1, 2]))
+    return spec, rr
+
+
+def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--seeds":
+        seeds = [int(a) for a in sys.argv[2].split(",")]
+    else:
+        seeds = range(*((int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)))
+    bad = 0
+    for seed in seeds:
+        spec, rr = scene(seed)
+        o = O.OracleScene(spec)
+        ref = o.render(rr_start_bounce=rr)
+        o.close()
+        g = api.GpuScene(spec)
+        msg = []
+        for mode in (0, 1, 2):
+            res, st = g.render(box_precision=mode, rr_start_bounce=rr, collect_stats=1)
+            ids = int((res["prim_id"] != ref["prim_id"]).sum())
+            with np.errstate(invalid="ignore"):
+                rel = np.abs(res["radiance"] - ref["radiance"]) / np.maximum(1.0, np.abs(ref["radiance"]))
+            nan_mismatch = int((np.isnan(res["radiance"]) != np.isnan(ref["radiance"])).sum())
+            worst = float(np.nanmax(rel)) if np.isfinite(rel).any() else 0.0
+            q = int((res["rgb8"] != ref["rgb8"]).sum())
+            ok = ids == 0 and worst <= 1e-12 and nan_mismatch == 0 and q == 0
+            bad += not ok
+            msg.append(f"m{mode}: ids {ids} rel {worst:.1e} nan {nan_mismatch} q {q} lit {st.rays_literal} {'OK' if ok else 'MISMATCH'}")
+        g.close()
+        kinds = [c[0] for c in spec.config_objects]
+        print(seed, f"{spec.width}x{spec.height}x{spec.spp} mb{spec.max_bounces} lt{spec.leaf_threshold} d{spec.bvh_max_depth} rr{rr}",
+              f"sph{kinds.count('sphere')} pl{kinds.count('plane')} L{len(spec.lights)} sky{spec.sky[0] if spec.sky else '-'}", "|", " | ".join(msg), flush=True)
+    print("mismatching (seed, mode) pairs:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
