@@ -59,6 +59,9 @@ static_assert(sizeof(DLight) == 64, "DLight must be 64 bytes");
 // ---------------------------------------------------------------- FP64 3-vectors (Core/Vec3.hs:53-111)
 struct d3 { double x, y, z; };
 #define RT_DEV __device__ __forceinline__
+#ifndef RT_NOINLINE
+#define RT_NOINLINE __attribute__((noinline))   // out-of-line helpers (rare paths); -DRT_NOINLINE= inlines them (experiment)
+#endif
 RT_DEV d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_DEV d3 ld3(const double *p) { return mk3(p[0], p[1], p[2]); }
 RT_DEV d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }

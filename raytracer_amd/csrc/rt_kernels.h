@@ -108,7 +108,7 @@ RT_COLD void camera_ray(const KFrame &fr, int px, int py, uint32_t pixel, uint32
 
 // equirect coordinates of a unit direction (SkySphere.hs:35-36).  Kept OUT of line on purpose: the FP64 atan2/asin
 // bodies need ~100 temporaries, which would otherwise set the register allocation of the whole render kernel.
-__device__ __attribute__((noinline)) double2 sky_uv(double nx, double ny, double nz) {
+__device__ RT_NOINLINE double2 sky_uv(double nx, double ny, double nz) {
   const double dy = fmax(-1.0, fmin(1.0, ny));
   double2 r;
   r.x = 0.5 + atan2(nz, nx) / (2 * 3.14159265358979323846);
@@ -343,7 +343,7 @@ RT_DEV int hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, do
 // candidate hits on spheres of radius <= 0 (inside-out or point-sized boxes).
 // `stk`: this lane's column of 3 * (tree depth) rows of 64 doubles in global memory (ref, lo, hi of the pending second children).
 struct LitHit { double t; int best; };
-__device__ __attribute__((noinline)) LitHit literal_hit(const DNode<double> *nodes, const DPrim *prims, int root_ref, double *stk,
+__device__ RT_NOINLINE LitHit literal_hit(const DNode<double> *nodes, const DPrim *prims, int root_ref, double *stk,
                                                         double ox, double oy, double oz, double dx, double dy, double dz,
                                                         double tmin, double tmax) {
   const d3 ro = mk3(ox, oy, oz), rd = mk3(dx, dy, dz);

@@ -117,7 +117,7 @@ RT_DEV uint32_t fastdiv24(uint32_t n, uint32_t d, float rcp) {
 }
 
 // gamma correction c ** gamma (Trace.hs:103-105), out of line: the FP64 pow body must not set the kernel's register budget
-__device__ __attribute__((noinline)) double pow_gamma(double c, double g) { return pow(c, g); }
+__device__ RT_NOINLINE double pow_gamma(double c, double g) { return pow(c, g); }
 
 // The two parameter structs are 720 bytes of kernel arguments.  Held in SGPRs for the whole kernel they overflow the
 // scalar register file (107 SGPRs were spilled into VGPR lanes and read back with v_readlane inside the NODE and PRIM
@@ -142,7 +142,7 @@ __device__ __attribute__((noinline)) double pow_gamma(double c, double g) { retu
 // first (BVH.hs:132); a child's clipped interval starts at max(its own slab entry, 0.001) whatever its ancestors
 // clipped, because nested boxes give nested slab intervals.  Out of line and rare: duplicated objects (the reference
 // lists config triangles twice, SceneParser.hs:67-73) and rays through shared edges or vertices.
-__device__ __attribute__((noinline)) bool tie_candidate_wins(const int32_t *leaf_anc, const int32_t *ref_anc, const int32_t *ref_depth,
+__device__ RT_NOINLINE bool tie_candidate_wins(const int32_t *leaf_anc, const int32_t *ref_anc, const int32_t *ref_depth,
                                                              const DNode<double> *ref_nodes, double ox, double oy, double oz,
                                                              double dx, double dy, double dz, int cand, int cur) {
   const int a = leaf_anc[cur], c = leaf_anc[cand];
@@ -378,7 +378,168 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
     if (n_act == 0) break;                                 // nothing in flight (every waiting lane was finished above) and the refill found nothing: frame done
     if (STATS && lane == 0) st[STAT_LIVE] += (uint32_t)n_act;
 
-    if (n_done * RT_SHADE_DEN >= n_act * RT_SHADE_NUM || n_node + n_leaf == 0) {
+    // The traversal bodies and SHADE are two guarded blocks in a row, not one if / else-if / else chain.  The compiler linearises a
+    // chain of uniform branches around divergent code into blocks joined by "flow" merges whose skipped side is undefined, and the
+    // ray, its box constants and the shading state (redefined by SHADE only) then lived in two register sets, reconciled by ~37
+    // register copies at the end of EVERY trip of this loop, NODE and PRIM trips included (found in the ISA: tools/isa_counts.py).
+    // A guarded block merges its results with the values that reach it, in place.  `trip` is made opaque between the blocks so
+    // that they are not threaded back into a chain.  (NODE, PRIM and SHADE as three guarded blocks removes the last copies too
+    // but costs 6-8 more spilled VGPRs, with reloads in the PRIM body: 47.0 ms against 43.0 for this form and 44.2 for the chain.)
+    int trip = (n_done * RT_SHADE_DEN >= n_act * RT_SHADE_NUM || n_node + n_leaf == 0) ? 2
+               : (n_node * RT_NODE_WEIGHT >= n_leaf * RT_LEAF_WEIGHT ? 0 : 1);
+    trip = __builtin_amdgcn_readfirstlane(trip);
+    asm volatile("" : "+s"(trip));
+    if (trip == 0) {
+      // ================================================= NODE step (BVH.hs:123-143)
+      if (STATS) st[STAT_IT_NODE]++;
+      RT_TICK(0);
+      RT_MARK("NODE_BEGIN");
+#pragma unroll
+      for (int it = 0; it < NODE_UNROLL; ++it) {
+        bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
+        if (SPEC) {                                          // postpone a freshly reached leaf and go on with the next stack entry
+          const bool spec = (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX && pend == 0 && sp > 0;
+          pend = spec ? cur : pend;
+          pp = pp || spec;
+        }
+        const bool isn = cur >= 0;
+        if (STATS && isn) st[STAT_NODES]++;
+        bool hL, hR;
+        BT tL, tR;
+        int refL = 0, refR = 0;
+        if constexpr (sizeof(BT) == 4) {
+          // Lanes that are not at a node read node 0 (always present; a broadcast) instead of being masked off:
+          // no zero-initialised registers, no exec-mask branch around the loads; their results are discarded by `isn`.
+          float4 q0, q1, q2;
+          int2 q3;
+          const int ni = isn ? cur : 0;
+          if (ni < top_nodes_v) {                            // top of the tree: the workgroup's LDS copy (ds_read_b128)
+            const float4 *p = lnodes + 4 * ni;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
+            asm volatile("" ::: "memory");                   // keep this an LDS load: do not merge with the global path into a FLAT load
+            if (STATS && isn) st[STAT_TOPHIT]++;
+          } else {                                           // scalar base + 32-bit lane offset
+            const char *p = (const char *)nodes + (size_t)((uint32_t)ni << 6);
+            q0 = *(const float4 *)p; q1 = *(const float4 *)(p + 16); q2 = *(const float4 *)(p + 32); q3 = *(const int2 *)(p + 48);
+          }
+          const float bxL[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+          const float bxR[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+          hL = box_test(br, bxL, tminb, tmaxb, tL) && isn;
+          hR = box_test(br, bxR, tminb, tmaxb, tR) && isn;
+          refL = q3.x; refR = q3.y;
+        } else {
+          const DNode<BT> nd = nodes[isn ? cur : 0];
+          hL = box_test(br, nd.box, tminb, tmaxb, tL) && isn;
+          hR = box_test(br, nd.box + 6, tminb, tmaxb, tR) && isn;
+          refL = nd.ref[0]; refR = nd.ref[1];
+        }
+        const bool lf = tL < tR;                             // BVH.hs:132: nearer child first, tie => right first
+        if (hL && hR) {                                      // push the farther child with its entry distance
+          const BT ts = lf ? tR : tL;
+          float tsf;
+          if constexpr (sizeof(BT) == 8) tsf = __double2float_rd((double)ts); else tsf = (float)ts;
+          const uint2 ent = make_uint2((uint32_t)(lf ? refR : refL), __float_as_uint(tsf));
+          if (sp < RT_STACK_LDS) stack[sp * 64] = ent; else ovf[(sp - RT_STACK_LDS) * 64] = ent;
+          ++sp;
+        }
+        cur = (hL || hR) ? ((hL && (lf || !hR)) ? refL : refR) : cur;
+        pp = pp || (isn && !(hL || hR));
+        RT_POP2(pp);
+      }
+      RT_TICK(1);
+    } else if (trip == 1) {
+      // ================================================= PRIM step (closestHitList, HitHelpers.hs:11-16)
+      RT_MARK("NODE_END");
+      if (STATS) st[STAT_IT_PRIM]++;
+      RT_TICK(0);
+      RT_MARK("PRIM_BEGIN");
+#pragma unroll
+      for (int it = 0; it < PRIM_UNROLL; ++it) {
+        const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
+        const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX;
+        const int pi = ~(use_p ? pend : cur);
+        // lanes not in a leaf read primitive 0 (always present) and discard the result: see the NODE body
+        const DPrim P = *(const DPrim *)((const char *)sc.tprims + (size_t)((uint32_t)(isl ? pi : 0) * 80u));
+        const uint32_t kind = P.kind & DPRIM_KIND_MASK;
+        // Moller-Trumbore without early exits (Triangle.hs:30-53): same operations, same order, the rejections become one predicate
+        double t;
+        bool h, lit_done = false;
+        {
+          const d3 p0 = mk3(P.d[0], P.d[1], P.d[2]), e1 = mk3(P.d[3], P.d[4], P.d[5]), e2 = mk3(P.d[6], P.d[7], P.d[8]);
+          const d3 hh = cross3(rd, e2);                      // :34
+          const double a = dot3(e1, hh);                     // :35
+          const double f = 1.0 / a;                          // :39
+          const d3 sv = ro - p0;                             // :40
+          const double u = f * dot3(sv, hh);                 // :41
+          const d3 q = cross3(sv, e1);                       // :45
+          const double v = f * dot3(rd, q);                  // :46
+          t = f * dot3(e2, q);                               // :50
+          h = !(fabs(a) < 1e-8) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && (t >= RT_TMIN && t <= best_t);   // :36,42,47,53
+        }
+        if (STATS && isl && kind == RT_PRIM_TRIANGLE) st[STAT_TRI]++;
+        if (__ballot(isl && kind != RT_PRIM_TRIANGLE) != 0ull) {   // wave-uniform: leaves with spheres/planes are rare
+          // The ray enters this branch through an opaque copy: otherwise the compiler hoists what depends on the ray alone
+          // (the plane's three FP64 reciprocals 1/d and its parallel-axis tests, the sphere's d.d: ~55 of ~190 VALU
+          // instructions) in front of the branch and every triangle test pays for it.
+          d3 ro_ = ro, rd_ = rd;
+          asm volatile("" : "+v"(ro_.x), "+v"(ro_.y), "+v"(ro_.z), "+v"(rd_.x), "+v"(rd_.y), "+v"(rd_.z));
+          int ps = PLANE_MISS;
+          if (isl && kind == RT_PRIM_SPHERE) {
+            if (STATS) st[STAT_SPHERE]++;
+            h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t);
+            // A sphere of negative radius lies outside its own (inside-out) box c -+ r (Sphere.hs:20-22), and that box is not
+            // inside its ancestors' boxes either (a union by min / max does not contain the hull of an inside-out box); a
+            // sphere of radius 0 is a point on the faces of its own box, where every hit is rounding noise.  Both are seen only
+            // through the interval the reference's traversal hands their leaf (the chain of clipped ancestor intervals), so
+            // a candidate hit settles the whole query with the literal walk.  d[6] < 0: the leaf is the root (raw interval).
+            if (h && !(P.d[3] > 0.0) && P.d[6] >= 0.0) { ps = PLANE_LITERAL; h = false; }
+          } else if (isl && kind == RT_PRIM_PLANE) {
+            if (STATS) st[STAT_PLANE]++;
+            ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);
+            h = ps == PLANE_HIT;
+          }
+          {
+            if (ps == PLANE_LITERAL) {
+              // The plane is crossed beyond its leaf box's exit: the reference sees it only if that leaf is visited second
+              // and its sibling produced a hit (BVH.hs:137-138) - a property of the reference's traversal, so the whole
+              // query is answered by the literal walk of the reference's tree and this lane's traversal ends here.
+              RT_COLD_ARGS();
+              if (STATS) st[STAT_LITERAL]++;
+              const LitHit lh = literal_hit((const DNode<double> *)sc.ref_nodes64, sc.prims, sc.ref_root_ref, rec + (size_t)fr.lit_row * 64,
+                                            ro_.x, ro_.y, ro_.z, rd_.x, rd_.y, rd_.z, RT_TMIN, li >= 0 ? best_t : RT_TMAX);
+              best = lh.best; best_t = lh.t; tmaxb = tmax_for_boxes<BT>(lh.t);
+              lit_done = true;
+            }
+          }
+        }
+        h = h && isl;
+        // FAST: this tree's order is not the reference's.  FP32 boxes on the reference's tree: two children's entry distances
+        // can compare differently after rounding, so the visiting order is not always the reference's either.  Both settle
+        // exact ties (duplicated objects) the reference's way; the FP64 boxes visit in its order and need no rule.
+        if constexpr (FAST || sizeof(BT) == 4) {
+          const bool tie = h && li < 0 && best >= 0 && t == best_t;
+          if (__ballot(tie) != 0ull) {
+            if (tie) h = tie_candidate_wins(sc.leaf_anc, sc.ref_anc, sc.ref_depth, (const DNode<double> *)sc.ref_nodes64,
+                                            ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, FAST ? (int)P.mat : pi, best);
+          }
+        }
+        best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
+        best = h ? (FAST ? P.mat : pi) : best;               // FAST: the slot holds the primitive's index in the reference's order
+        tmaxb = h ? tmax_for_boxes<BT>(t) : tmaxb;
+        const bool blocked = h && li >= 0;                   // shadow ray: any hit blocks (Light.hs:30-32)
+        const bool last = (P.kind & DPRIM_LAST) != 0u;
+        if (SPEC) pend = use_p ? ((blocked || last) ? 0 : pend - 1) : (blocked ? 0 : pend);
+        cur = isl ? (blocked ? CUR_DONE : ((last || use_p) ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)
+        bool pp = isl && !use_p && !blocked && last;
+        RT_POP2(pp);
+        cur = lit_done ? CUR_DONE : cur;                     // (rare) the query was answered by literal_hit
+        sp = lit_done ? 0 : sp;
+        if (SPEC) pend = lit_done ? 0 : pend;
+      }
+      RT_TICK(2);
+    }
+    asm volatile("" : "+s"(trip));
+    if (trip == 2) {
       // ================================================= SHADE step: lanes whose query finished
       if (STATS) st[STAT_IT_SHADE]++;
       RT_TICK(0);
@@ -569,154 +730,6 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       RT_MARK("SHADE_END");
       RT_TICK(3);
       RT_MARK("REFILL_END");
-    } else if (n_node * RT_NODE_WEIGHT >= n_leaf * RT_LEAF_WEIGHT) {
-      // ================================================= NODE step (BVH.hs:123-143)
-      if (STATS) st[STAT_IT_NODE]++;
-      RT_TICK(0);
-      RT_MARK("NODE_BEGIN");
-#pragma unroll
-      for (int it = 0; it < NODE_UNROLL; ++it) {
-        bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
-        if (SPEC) {                                          // postpone a freshly reached leaf and go on with the next stack entry
-          const bool spec = (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX && pend == 0 && sp > 0;
-          pend = spec ? cur : pend;
-          pp = pp || spec;
-        }
-        const bool isn = cur >= 0;
-        if (STATS && isn) st[STAT_NODES]++;
-        bool hL, hR;
-        BT tL, tR;
-        int refL = 0, refR = 0;
-        if constexpr (sizeof(BT) == 4) {
-          // Lanes that are not at a node read node 0 (always present; a broadcast) instead of being masked off:
-          // no zero-initialised registers, no exec-mask branch around the loads; their results are discarded by `isn`.
-          float4 q0, q1, q2;
-          int2 q3;
-          const int ni = isn ? cur : 0;
-          if (ni < top_nodes_v) {                            // top of the tree: the workgroup's LDS copy (ds_read_b128)
-            const float4 *p = lnodes + 4 * ni;
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
-            asm volatile("" ::: "memory");                   // keep this an LDS load: do not merge with the global path into a FLAT load
-            if (STATS && isn) st[STAT_TOPHIT]++;
-          } else {                                           // scalar base + 32-bit lane offset
-            const char *p = (const char *)nodes + (size_t)((uint32_t)ni << 6);
-            q0 = *(const float4 *)p; q1 = *(const float4 *)(p + 16); q2 = *(const float4 *)(p + 32); q3 = *(const int2 *)(p + 48);
-          }
-          const float bxL[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-          const float bxR[6] = {q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-          hL = box_test(br, bxL, tminb, tmaxb, tL) && isn;
-          hR = box_test(br, bxR, tminb, tmaxb, tR) && isn;
-          refL = q3.x; refR = q3.y;
-        } else {
-          const DNode<BT> nd = nodes[isn ? cur : 0];
-          hL = box_test(br, nd.box, tminb, tmaxb, tL) && isn;
-          hR = box_test(br, nd.box + 6, tminb, tmaxb, tR) && isn;
-          refL = nd.ref[0]; refR = nd.ref[1];
-        }
-        const bool lf = tL < tR;                             // BVH.hs:132: nearer child first, tie => right first
-        if (hL && hR) {                                      // push the farther child with its entry distance
-          const BT ts = lf ? tR : tL;
-          float tsf;
-          if constexpr (sizeof(BT) == 8) tsf = __double2float_rd((double)ts); else tsf = (float)ts;
-          const uint2 ent = make_uint2((uint32_t)(lf ? refR : refL), __float_as_uint(tsf));
-          if (sp < RT_STACK_LDS) stack[sp * 64] = ent; else ovf[(sp - RT_STACK_LDS) * 64] = ent;
-          ++sp;
-        }
-        cur = (hL || hR) ? ((hL && (lf || !hR)) ? refL : refR) : cur;
-        pp = pp || (isn && !(hL || hR));
-        RT_POP2(pp);
-      }
-      RT_TICK(1);
-    } else {
-      // ================================================= PRIM step (closestHitList, HitHelpers.hs:11-16)
-      RT_MARK("NODE_END");
-      if (STATS) st[STAT_IT_PRIM]++;
-      RT_TICK(0);
-      RT_MARK("PRIM_BEGIN");
-#pragma unroll
-      for (int it = 0; it < PRIM_UNROLL; ++it) {
-        const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
-        const bool isl = use_p || (uint32_t)cur > (uint32_t)CUR_SPECIAL_MAX;
-        const int pi = ~(use_p ? pend : cur);
-        // lanes not in a leaf read primitive 0 (always present) and discard the result: see the NODE body
-        const DPrim P = *(const DPrim *)((const char *)sc.tprims + (size_t)((uint32_t)(isl ? pi : 0) * 80u));
-        const uint32_t kind = P.kind & DPRIM_KIND_MASK;
-        // Moller-Trumbore without early exits (Triangle.hs:30-53): same operations, same order, the rejections become one predicate
-        double t;
-        bool h, lit_done = false;
-        {
-          const d3 p0 = mk3(P.d[0], P.d[1], P.d[2]), e1 = mk3(P.d[3], P.d[4], P.d[5]), e2 = mk3(P.d[6], P.d[7], P.d[8]);
-          const d3 hh = cross3(rd, e2);                      // :34
-          const double a = dot3(e1, hh);                     // :35
-          const double f = 1.0 / a;                          // :39
-          const d3 sv = ro - p0;                             // :40
-          const double u = f * dot3(sv, hh);                 // :41
-          const d3 q = cross3(sv, e1);                       // :45
-          const double v = f * dot3(rd, q);                  // :46
-          t = f * dot3(e2, q);                               // :50
-          h = !(fabs(a) < 1e-8) && !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && (t >= RT_TMIN && t <= best_t);   // :36,42,47,53
-        }
-        if (STATS && isl && kind == RT_PRIM_TRIANGLE) st[STAT_TRI]++;
-        if (__ballot(isl && kind != RT_PRIM_TRIANGLE) != 0ull) {   // wave-uniform: leaves with spheres/planes are rare
-          // The ray enters this branch through an opaque copy: otherwise the compiler hoists what depends on the ray alone
-          // (the plane's three FP64 reciprocals 1/d and its parallel-axis tests, the sphere's d.d: ~55 of ~190 VALU
-          // instructions) in front of the branch and every triangle test pays for it.
-          d3 ro_ = ro, rd_ = rd;
-          asm volatile("" : "+v"(ro_.x), "+v"(ro_.y), "+v"(ro_.z), "+v"(rd_.x), "+v"(rd_.y), "+v"(rd_.z));
-          int ps = PLANE_MISS;
-          if (isl && kind == RT_PRIM_SPHERE) {
-            if (STATS) st[STAT_SPHERE]++;
-            h = hit_sphere(P, ro_, rd_, RT_TMIN, best_t, t);
-            // A sphere of negative radius lies outside its own (inside-out) box c -+ r (Sphere.hs:20-22), and that box is not
-            // inside its ancestors' boxes either (a union by min / max does not contain the hull of an inside-out box); a
-            // sphere of radius 0 is a point on the faces of its own box, where every hit is rounding noise.  Both are seen only
-            // through the interval the reference's traversal hands their leaf (the chain of clipped ancestor intervals), so
-            // a candidate hit settles the whole query with the literal walk.  d[6] < 0: the leaf is the root (raw interval).
-            if (h && !(P.d[3] > 0.0) && P.d[6] >= 0.0) { ps = PLANE_LITERAL; h = false; }
-          } else if (isl && kind == RT_PRIM_PLANE) {
-            if (STATS) st[STAT_PLANE]++;
-            ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);
-            h = ps == PLANE_HIT;
-          }
-          {
-            if (ps == PLANE_LITERAL) {
-              // The plane is crossed beyond its leaf box's exit: the reference sees it only if that leaf is visited second
-              // and its sibling produced a hit (BVH.hs:137-138) - a property of the reference's traversal, so the whole
-              // query is answered by the literal walk of the reference's tree and this lane's traversal ends here.
-              RT_COLD_ARGS();
-              if (STATS) st[STAT_LITERAL]++;
-              const LitHit lh = literal_hit((const DNode<double> *)sc.ref_nodes64, sc.prims, sc.ref_root_ref, rec + (size_t)fr.lit_row * 64,
-                                            ro_.x, ro_.y, ro_.z, rd_.x, rd_.y, rd_.z, RT_TMIN, li >= 0 ? best_t : RT_TMAX);
-              best = lh.best; best_t = lh.t; tmaxb = tmax_for_boxes<BT>(lh.t);
-              lit_done = true;
-            }
-          }
-        }
-        h = h && isl;
-        // FAST: this tree's order is not the reference's.  FP32 boxes on the reference's tree: two children's entry distances
-        // can compare differently after rounding, so the visiting order is not always the reference's either.  Both settle
-        // exact ties (duplicated objects) the reference's way; the FP64 boxes visit in its order and need no rule.
-        if constexpr (FAST || sizeof(BT) == 4) {
-          const bool tie = h && li < 0 && best >= 0 && t == best_t;
-          if (__ballot(tie) != 0ull) {
-            if (tie) h = tie_candidate_wins(sc.leaf_anc, sc.ref_anc, sc.ref_depth, (const DNode<double> *)sc.ref_nodes64,
-                                            ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, FAST ? (int)P.mat : pi, best);
-          }
-        }
-        best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
-        best = h ? (FAST ? P.mat : pi) : best;               // FAST: the slot holds the primitive's index in the reference's order
-        tmaxb = h ? tmax_for_boxes<BT>(t) : tmaxb;
-        const bool blocked = h && li >= 0;                   // shadow ray: any hit blocks (Light.hs:30-32)
-        const bool last = (P.kind & DPRIM_LAST) != 0u;
-        if (SPEC) pend = use_p ? ((blocked || last) ? 0 : pend - 1) : (blocked ? 0 : pend);
-        cur = isl ? (blocked ? CUR_DONE : ((last || use_p) ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)
-        bool pp = isl && !use_p && !blocked && last;
-        RT_POP2(pp);
-        cur = lit_done ? CUR_DONE : cur;                     // (rare) the query was answered by literal_hit
-        sp = lit_done ? 0 : sp;
-        if (SPEC) pend = lit_done ? 0 : pend;
-      }
-      RT_TICK(2);
     }
   }
 #undef RT_BEGIN_QUERY

@@ -4,7 +4,7 @@ triangles, spheres (a few with negative or zero radius), planes of random point 
 glass / metal / emissive materials, point and directional lights, gradient / solid / LDR / HDR sky, thin lens, random
 leafThreshold / bvhMaxDepth / maxBounces, Russian roulette on some seeds; all three box_precision modes.
 Prints one line per seed; exit status 1 if any pixel's id differs or any radiance differs by more than 1e-12 (relative to
-max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712"""
+max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big]"""
 import os
 import sys
 
@@ -15,9 +15,10 @@ from oracle import oracle as O                     # noqa: E402
 from raytracer_amd import api, scenes              # noqa: E402
 
 
-def scene(seed):
+def scene(seed, big=False):
+    """big: 3000 / 40000 triangles, frames around 300 x 200, up to 30 bounces (deep trees, many refills per wave)."""
     rng = np.random.default_rng(seed)
-    n_tris = int(rng.choice([30, 300, 3000]))
+    n_tris = int(rng.choice([3000, 40000] if big else [30, 300, 3000]))
     ctr = rng.uniform([-4, -0.5, -4], [4, 4, 4], size=(n_tris, 3))
     size = np.where(rng.random(n_tris) < 0.02, 6.0, rng.uniform(0.05, 0.7, n_tris))
     tri = ctr[:, None, :] + rng.uniform(-1, 1, size=(n_tris, 3, 3)) * size[:, None, None]
@@ -50,12 +51,14 @@ def scene(seed):
     bg = ({"tag": "Gradient", "color1": [1.0, 1.0, 1.0], "color2": [0.5, 0.7, 1.0]} if rng.random() < 0.5
           else {"tag": "SolidColor", "color": list(rng.uniform(0, 1.5, 3))})
     spec = scenes.SceneSpec(
-        name=f"fz{seed}", width=int(rng.integers(40, 160)), height=int(rng.integers(24, 90)), spp=int(rng.integers(1, 5)),
+        name=f"fz{seed}", width=int(rng.integers(200, 400) if big else rng.integers(40, 160)),
+        height=int(rng.integers(120, 260) if big else rng.integers(24, 90)), spp=int(rng.integers(1, 9 if big else 5)),
         antialiasing=bool(rng.random() < 0.8), gamma=float(rng.choice([1.0, 0.8, 2.2])), exposure=float(rng.uniform(0.5, 2.0)),
         background=bg,
         camera={"lookFrom": list(rng.uniform(-9, 9, 3) + [0, 3, 0]), "lookAt": [0.0, 1.0, 0.0], "vUp": [0.0, 1.0, 0.0],
                 "vfov": float(rng.uniform(30, 90)), "aperture": float(rng.choice([0.0, 0.0, 0.3])), "focusDist": 3.0},
-        max_bounces=int(rng.integers(0, 8)), bvh_max_depth=int(rng.choice([0, 2, 6, 12, 32])), leaf_threshold=int(rng.integers(1, 9)),
+        max_bounces=int(rng.choice([1, 5, 10, 30]) if big else rng.integers(0, 8)),
+        bvh_max_depth=int(rng.choice([12, 20, 32, 50]) if big else rng.choice([0, 2, 6, 12, 32])), leaf_threshold=int(rng.integers(1, 9)),
         materials=mats, lights=lights, config_objects=cfg,
         obj_meshes=[scenes.ObjMesh(tri.reshape(-1, 3), np.arange(3 * n_tris).reshape(n_tris, 3), fm, tuple(rng.uniform(-1, 1, 3)))],
         seed=int(rng.integers(0, 2 ** 40)))
@@ -71,15 +74,18 @@ def scene(seed):
 
 
 def main():
+    big = "--big" in sys.argv
+    if big:
+        sys.argv.remove("--big")
     if len(sys.argv) > 2 and sys.argv[1] == "--seeds":
         seeds = [int(a) for a in sys.argv[2].split(",")]
     else:
         seeds = range(*((int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)))
     bad = 0
     for seed in seeds:
-        spec, rr = scene(seed)
+        spec, rr = scene(seed, big)
         o = O.OracleScene(spec)
-        ref = o.render(rr_start_bounce=rr)
+        ref = o.render(rr_start_bounce=rr, n_threads=min(16, os.cpu_count() or 8))
         o.close()
         g = api.GpuScene(spec)
         msg = []
