@@ -413,7 +413,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           float4 q0, q1, q2;
           int2 q3;
           const int ni = isn ? cur : 0;
-          if (ni < top_nodes_v) {                            // top of the tree: the workgroup's LDS copy (ds_read_b128)
+          if (RT_TOP_NODES_MAX > 0 && ni < top_nodes_v) {   // top of the tree: the workgroup's LDS copy (ds_read_b128)
             const float4 *p = lnodes + 4 * ni;
             q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = *(const int2 *)(p + 3);
             asm volatile("" ::: "memory");                   // keep this an LDS load: do not merge with the global path into a FLAT load
