@@ -207,13 +207,20 @@ RT_DEV void make_boxray(BoxRay<double> &b, d3 o, d3 d, float) {
   b.px = fabs(d.x) < 1e-8; b.py = fabs(d.y) < 1e-8; b.pz = fabs(d.z) < 1e-8;      // :21
   b.ix = 1.0 / d.x; b.iy = 1.0 / d.y; b.iz = 1.0 / d.z;                           // :24
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_DEV float rcp_approx(float v) { return __builtin_amdgcn_rcpf(v); }
+#else
+RT_DEV float rcp_approx(float v) { return 1.0f / v; }       // (the host pass only parses the kernels)
+#endif
 RT_DEV float safe_dir(float v) { return fabsf(v) < 1e-30f ? (v < 0.0f ? -1e-30f : 1e-30f) : v; }
 RT_DEV void make_boxray(BoxRay<float> &b, d3 o, d3 d, float rscene) {
   float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
   float omax = fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz)));
   // reachable region: |coord| <= omax + 1e4 (t <= 10000, |d| ~ 1), clipped to the scene
   float m = 9.5367431640625e-7f * (fminf(rscene, omax + 1.0e4f) + omax) + 1e-30f;   // 2^-20 * extent
-  b.ix = 1.0f / safe_dir((float)d.x); b.iy = 1.0f / safe_dir((float)d.y); b.iz = 1.0f / safe_dir((float)d.z);
+  // 1 / d by v_rcp_f32 (1 ulp) instead of an IEEE division (10 instructions each): the factor (1 + e) multiplies a whole slab
+  // distance (lo - o -+ m) * i, and e * |lo - o| <= 2^-23 * extent is an eighth of the margin m
+  b.ix = rcp_approx(safe_dir((float)d.x)); b.iy = rcp_approx(safe_dir((float)d.y)); b.iz = rcp_approx(safe_dir((float)d.z));
   b.ax = (ox + m) * b.ix; b.ay = (oy + m) * b.iy; b.az = (oz + m) * b.iz;
   b.bx = (ox - m) * b.ix; b.by = (oy - m) * b.iy; b.bz = (oz - m) * b.iz;
 }
@@ -247,7 +254,10 @@ template <typename BT> RT_DEV BT tmax_for_boxes(double best_t);
 template <> RT_DEV double tmax_for_boxes<double>(double best_t) { return best_t; }
 // FP32: rounded up and already widened by the slack, so that the pop-time cull needs no multiplication (the slab test
 // then applies the slack twice to this bound: still a superset)
-template <> RT_DEV float tmax_for_boxes<float>(double best_t) { return __double2float_ru(best_t) * RT_SLACK; }
+// (round-to-nearest conversion, 0.5 ulp, covered by three more ulps of slack: two instructions; a directed rounding is a
+// 13-instruction sequence here, run at every accepted hit)
+#define RT_SLACK_UP 1.0000013f
+template <> RT_DEV float tmax_for_boxes<float>(double best_t) { return (float)best_t * RT_SLACK_UP; }
 template <typename BT> RT_DEV BT tmin_for_boxes();
 template <> RT_DEV double tmin_for_boxes<double>() { return RT_TMIN; }
 template <> RT_DEV float tmin_for_boxes<float>() { return 0.00099999f; }
