@@ -100,6 +100,11 @@ enum { LR_ATT = 0, LR_FA = 3, LR_FL = 6, LR_FH = 9, LR_SB = 12 /* int2: sample, 
 enum { PR_UDIR = 0, PR_NRM = 3, PR_S = 6 /* Russian roulette (opt-in extension): the weight of everything deeper */, PR_ROWS = 7 };
 #define HITP_FRONT ((int)0x80000000)   // lane register hitp: the primitive of the path's current hit | front-face bit
 
+// The cold rows are global memory, and SHADE says so to the compiler: its opaque copy of the row pointer had lost the address
+// space, and FLAT loads / stores also count against the LDS counter, so that a wait for the record's LDS rows waited for them too.
+typedef __attribute__((address_space(1))) double gdouble;
+RT_DEV d3 rec_ld(const gdouble *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
+RT_DEV void rec_st(gdouble *r, int row, d3 v) { r[row * 64] = v.x; r[(row + 1) * 64] = v.y; r[(row + 2) * 64] = v.z; }
 RT_DEV d3 rec_ld(const double *r, int row) { return mk3(r[row * 64], r[(row + 1) * 64], r[(row + 2) * 64]); }
 RT_DEV void rec_st(double *r, int row, d3 v) { r[row * 64] = v.x; r[(row + 1) * 64] = v.y; r[(row + 2) * 64] = v.z; }
 RT_DEV int2 rec_ldi(const double *r, int row) { return *(const int2 *)(r + row * 64); }
@@ -545,8 +550,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       RT_TICK(0);
       RT_MARK("SHADE_BEGIN");
       if (is_done) {                                         // (every sub-block re-reads the arguments it needs: RT_COLD_ARGS)
-        double *r = rec;
-        asm volatile("" : "+v"(r) : : "memory");            // the record is re-read from memory, never carried in registers
+        double *r_ = rec;
+        asm volatile("" : "+v"(r_) : : "memory");           // the record is re-read from memory, never carried in registers
+        gdouble *r = (gdouble *)r_;
         const bool anyhit = li >= 0;
         const bool is_h = !anyhit && best >= 0;              // closest-hit query found a surface
         bool need_scatter = false, need_finish = false;
