@@ -240,7 +240,9 @@ RT_DEV bool box_test(const BoxRay<double> &r, const double *bx, double tmin, dou
   double texit = fmin(fmin(a1, b1), fmin(c1, tmax));               // :31
   return ok && tenter <= texit;                                    // :32
 }
+#ifndef RT_SLACK
 #define RT_SLACK 1.000001f
+#endif
 RT_DEV bool box_test(const BoxRay<float> &r, const float *bx, float tmin, float tmax, float &tenter) {
   float tlx = fmaf(bx[0], r.ix, -r.ax), thx = fmaf(bx[3], r.ix, -r.bx);
   float tly = fmaf(bx[1], r.iy, -r.ay), thy = fmaf(bx[4], r.iy, -r.by);
@@ -256,7 +258,9 @@ template <> RT_DEV double tmax_for_boxes<double>(double best_t) { return best_t;
 // then applies the slack twice to this bound: still a superset)
 // (round-to-nearest conversion, 0.5 ulp, covered by three more ulps of slack: two instructions; a directed rounding is a
 // 13-instruction sequence here, run at every accepted hit)
+#ifndef RT_SLACK_UP
 #define RT_SLACK_UP 1.0000013f
+#endif
 template <> RT_DEV float tmax_for_boxes<float>(double best_t) { return (float)best_t * RT_SLACK_UP; }
 template <typename BT> RT_DEV BT tmin_for_boxes();
 template <> RT_DEV double tmin_for_boxes<double>() { return RT_TMIN; }
