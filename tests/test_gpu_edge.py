@@ -63,3 +63,40 @@ def test_nothing_traced_and_directional_lights_only(need_gpu):
     spec.lights = [{"tag": "DirectionalLight", "direction": [0.2, -1.0, 0.1], "intensity": [0.7, 0.7, 0.6]},
                    {"tag": "DirectionalLight", "direction": [0.0, 1.0, 0.0], "intensity": [0.3, 0.3, 0.3]}]   # one from below: every term culled or blocked
     check(*both(spec))
+
+
+@pytest.mark.parametrize("case", ["far", "axis", "huge_scene", "tiny_scene"])
+def test_conservative_fp32_boxes_at_the_extremes(need_gpu, case):
+    """The FP32 slab test (origin margin, 1/d by v_rcp_f32, rounded interval end) must stay a superset of the reference's FP64 test
+    where its error terms are largest: a camera 20,000 units away looking through a 0.05-degree lens, rays exactly along an
+    axis (direction components 0 and 1e-17-ish), a scene 500 times larger around coordinates of 1e6 (one FP32 ulp there is 0.25),
+    and a scene a hundredth of the size (distances near the lower end 0.001 of the accepted interval)."""
+    spec = scenes.c3_blob988(width=96, height=64, spp=2)
+    spec.max_bounces = 3
+    cam = dict(spec.camera)
+    if case == "far":
+        look_from = np.array(cam["lookFrom"], dtype=float)
+        look_at = np.array(cam["lookAt"], dtype=float)
+        d = (look_from - look_at) / np.linalg.norm(look_from - look_at)
+        cam["lookFrom"] = list(look_at + 9000.0 * d)       # (beyond tmax = 10000 nothing is hit at all)
+        cam["vfov"] = 0.05
+    elif case == "axis":
+        cam["lookFrom"] = [0.0, 1.0, 6.0]; cam["lookAt"] = [0.0, 1.0, 0.0]; cam["vfov"] = 1e-6    # every primary ray is (0, 0, -1) to 1e-8
+        spec.antialiasing = False
+    elif case in ("huge_scene", "tiny_scene"):
+        s = 500.0 if case == "huge_scene" else 0.01        # (hits are accepted in [0.001, 10000] only: the scene has to stay inside)
+        off = np.array([3.0e6, -2.0e6, 1.0e6]) if case == "huge_scene" else np.zeros(3)
+        for m in spec.obj_meshes:                        # (c3: all geometry is in the OBJ meshes, no config objects)
+            m.verts = np.asarray(m.verts, dtype=float) * s
+            m.position = tuple(np.asarray(m.position, dtype=float) * s + off)
+        assert not spec.config_objects
+        cam["lookFrom"] = list(np.asarray(cam["lookFrom"], dtype=float) * s + off)
+        cam["lookAt"] = list(np.asarray(cam["lookAt"], dtype=float) * s + off)
+        if "focusDist" in cam:
+            cam["focusDist"] = cam["focusDist"] * s
+        for L in spec.lights:
+            if L["tag"] == "PointLight":
+                L["position"] = list(np.asarray(L["position"], dtype=float) * s + off)
+                L["intensity"] = list(np.asarray(L["intensity"], dtype=float) * s * s)
+    spec.camera = cam
+    check(*both(spec))
