@@ -125,6 +125,7 @@ __device__ RT_NOINLINE double2 sky_uv(double nx, double ny, double nz) {
 // A direction within ~1e-16 of a texel boundary may fall on the other side than libm's rounding puts it - the same class of
 // difference as between two libm implementations (ocml here, glibc under GHC).  If the estimate is ever off by more than
 // one texel (or NaN), the bracketing tests fail and the lane takes the libm path (sky_uv).
+#define SKY_NEAR_BOUNDARY 4e-15
 #define SKY_TAB_PAD 2      // the tables start at k = -SKY_TAB_PAD
 RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
   const int w = sc.sky_w, h = sc.sky_h;
@@ -142,9 +143,15 @@ RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
     i0 = i0 < 0 ? 0 : (i0 > w - 1 ? w - 1 : i0);
     const double2 *t = (const double2 *)sc.sky_u_tab + (i0 - 1 + SKY_TAB_PAD);          // boundaries i0-1 .. i0+2
     const double2 b0 = t[0], b1 = t[1], b2 = t[2], b3 = t[3];
-    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c1 = b1.x * n.z - b1.y * n.x >= 0.0;
-    const bool c2 = b2.x * n.z - b2.y * n.x >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
+    const double v1 = b1.x * n.z - b1.y * n.x, v2 = b2.x * n.z - b2.y * n.x;
+    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c1 = v1 >= 0.0;
+    const bool c2 = v2 >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
     ok = ok && c0 && !c3 && n.z != 0.0 && (mx == mx) && mx > 0.0f;   // z = +-0: atan2 tells +pi from -pi by the sign of zero, a cross product cannot
+    // A direction within rounding of a boundary belongs to whichever texel the reference's FLOATING-POINT u = 0.5 + atan2 / 2 pi falls
+    // into, not to the one exact geometry says: the lane takes the libm path.  This is not a measure-zero corner: a camera that looks
+    // exactly along an axis has a centre column of rays with x or z = +-1e-16 (rounding residue), and x = +-z on its diagonals
+    // (tools/fuzz_oracle.py --extreme).  u carries ~1 ulp of 1 = 1.1e-16, i.e. 7e-16 in angle.
+    ok = ok && fabs(v1) > SKY_NEAR_BOUNDARY && fabs(v2) > SKY_NEAR_BOUNDARY;
     i = (long long)i0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
   }
   {                                                                 // ---- row: FP32 estimate of asin(y) (Abramowitz-Stegun 4.4.45)
@@ -157,6 +164,7 @@ RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
     const double *t = sc.sky_v_tab + (j0 - 1 + SKY_TAB_PAD);                            // thresholds j0-1 .. j0+2
     const bool c0 = dy <= t[0], c1 = dy <= t[1], c2 = dy <= t[2], c3 = dy <= t[3];
     ok = ok && c0 && (!c3 || j0 + 2 > h);                           // (dy = -1 reaches the last threshold: clamped below)
+    ok = ok && fabs(dy - t[1]) > SKY_NEAR_BOUNDARY && fabs(dy - t[2]) > SKY_NEAR_BOUNDARY;   // as for the column: v = 0.5 - asin / pi carries ~1e-16
     j = (long long)j0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
   }
   if (!ok) {                                                        // never on a valid estimate; keeps the result defined

@@ -4,7 +4,7 @@ triangles, spheres (a few with negative or zero radius), planes of random point 
 glass / metal / emissive materials, point and directional lights, gradient / solid / LDR / HDR sky, thin lens, random
 leafThreshold / bvhMaxDepth / maxBounces, Russian roulette on some seeds; all three box_precision modes.
 Prints one line per seed; exit status 1 if any pixel's id differs or any radiance differs by more than 1e-12 (relative to
-max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big]"""
+max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme]"""
 import os
 import sys
 
@@ -15,7 +15,7 @@ from oracle import oracle as O                     # noqa: E402
 from raytracer_amd import api, scenes              # noqa: E402
 
 
-def scene(seed, big=False):
+def scene(seed, big=False, extreme=False):
     """big: 3000 / 40000 triangles, frames around 300 x 200, up to 30 bounces (deep trees, many refills per wave)."""
     rng = np.random.default_rng(seed)
     n_tris = int(rng.choice([3000, 40000] if big else [30, 300, 3000]))
@@ -70,20 +70,58 @@ def scene(seed, big=False):
     elif k < 0.5:
         spec.sky = scenes.sunset_sky(int(rng.integers(16, 300)), int(rng.integers(8, 150)), seed=seed)
     rr = int(rng.choice([0, 0, 0, 1, 2]))
+    if extreme:
+        # the FP32 box test's error terms at their largest: scene scaled by 0.01 ... 300 and moved up to 1e6 away from the origin
+        # (point lights keep their effect: intensity x scale^2), a long lens from far away, or a view exactly along an axis
+        sc = float(rng.choice([0.01, 0.1, 30.0, 300.0]))
+        off = rng.uniform(-1, 1, 3) * float(rng.choice([0.0, 1e3, 1e6]))
+        m = spec.obj_meshes[0]
+        m.verts = m.verts * sc
+        m.position = tuple(np.asarray(m.position) * sc + off)
+        cfg2 = []
+        for c in spec.config_objects:
+            if c[0] == "sphere":
+                cfg2.append(("sphere", list(np.asarray(c[1]) * sc + off), c[2] * sc, c[3]))
+            elif c[0] == "plane":
+                cfg2.append(("plane", list(np.asarray(c[1]) * sc + off), c[2], c[3]))
+            else:
+                cfg2.append(("triangle", list(np.asarray(c[1]) * sc + off), list(np.asarray(c[2]) * sc + off), list(np.asarray(c[3]) * sc + off), c[4]))
+        spec.config_objects = cfg2
+        for L in spec.lights:
+            if L["tag"] == "PointLight":
+                L["position"] = list(np.asarray(L["position"]) * sc + off)
+                L["intensity"] = list(np.asarray(L["intensity"]) * sc * sc)
+        cam = spec.camera
+        lf, la = np.asarray(cam["lookFrom"]) * sc + off, np.asarray(cam["lookAt"]) * sc + off
+        k = rng.random()
+        if k < 0.3:                                        # long lens
+            far = float(rng.choice([10.0, 100.0]))
+            lf = la + (lf - la) * far
+            cam["vfov"] = cam["vfov"] / far
+        elif k < 0.5:                                      # exactly along an axis
+            ax = int(rng.integers(0, 3))
+            d = np.zeros(3); d[ax] = float(rng.choice([-1.0, 1.0])) * np.linalg.norm(lf - la)
+            lf = la - d
+            if ax == 1:
+                cam["vUp"] = [0.0, 0.0, 1.0]
+        cam["lookFrom"], cam["lookAt"] = list(lf), list(la)
+        cam["focusDist"] = cam["focusDist"] * sc
+        cam["aperture"] = cam["aperture"] * sc
     return spec, rr
 
 
 def main():
-    big = "--big" in sys.argv
-    if big:
-        sys.argv.remove("--big")
+    big, extreme = "--big" in sys.argv, "--extreme" in sys.argv
+    for f in ("--big", "--extreme"):
+        if f in sys.argv:
+            sys.argv.remove(f)
     if len(sys.argv) > 2 and sys.argv[1] == "--seeds":
         seeds = [int(a) for a in sys.argv[2].split(",")]
     else:
         seeds = range(*((int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)))
     bad = 0
     for seed in seeds:
-        spec, rr = scene(seed, big)
+        spec, rr = scene(seed, big, extreme)
         o = O.OracleScene(spec)
         ref = o.render(rr_start_bounce=rr, n_threads=min(16, os.cpu_count() or 8))
         o.close()

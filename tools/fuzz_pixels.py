@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""For one seed of tools/fuzz_oracle.py: the pixels where the GPU (box_precision = argv[2]) and the oracle differ."""
+"""For one seed of tools/fuzz_oracle.py: the pixels where the GPU (box_precision = argv[2]) and the oracle differ.
+    python tools/fuzz_pixels.py <seed> <mode> [--big] [--extreme]"""
 import os
 import sys
 
@@ -12,7 +13,8 @@ from oracle import oracle as O                     # noqa: E402
 from raytracer_amd import api                      # noqa: E402
 
 seed, mode = int(sys.argv[1]), int(sys.argv[2])
-spec, rr = F.scene(seed)
+spec, rr = F.scene(seed, "--big" in sys.argv, "--extreme" in sys.argv)
+print("camera", spec.camera, "aa", spec.antialiasing, "sky", None if spec.sky is None else (spec.sky[0], spec.sky[1].shape), "mb", spec.max_bounces)
 o = O.OracleScene(spec)
 ref = o.render(rr_start_bounce=rr)
 g = api.GpuScene(spec)
