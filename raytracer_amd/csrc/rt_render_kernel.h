@@ -112,6 +112,24 @@ RT_DEV void rec_sti(double *r, int row, int a, int b) { *(int2 *)(r + row * 64) 
 #endif
 
 
+// Instruction-arbitration priority (s_setprio) of a wave while it runs a body.  NODE trips run above the rest: a node visit is a
+// chain of dependent LDS / L1 round trips with little arithmetic between them, and a wave that gets its next load out sooner hides
+// more of it behind the others' arithmetic (C4: kernel 41.8 -> 41.1 ms at any level above 0; PRIM or SHADE raised instead: no gain or a loss).
+#ifndef RT_PRIO_SHADE
+#define RT_PRIO_SHADE 0
+#endif
+#ifndef RT_PRIO_PRIM
+#define RT_PRIO_PRIM 0
+#endif
+#ifndef RT_PRIO_NODE
+#define RT_PRIO_NODE 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_PRIO(n) do { if (RT_PRIO_SHADE || RT_PRIO_NODE || RT_PRIO_PRIM) __builtin_amdgcn_s_setprio(n); } while (0)
+#else
+#define RT_PRIO(n) do { } while (0)
+#endif
+
 // n / d for n < 2^24 with rcp = 1.0f / d: float estimate, exact after the correction steps
 RT_DEV uint32_t fastdiv24(uint32_t n, uint32_t d, float rcp) {
   uint32_t q = (uint32_t)((float)n * rcp);
@@ -399,6 +417,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (STATS) st[STAT_IT_NODE]++;
       RT_TICK(0);
       RT_MARK("NODE_BEGIN");
+      RT_PRIO(RT_PRIO_NODE);
 #pragma unroll
       for (int it = 0; it < NODE_UNROLL; ++it) {
         bool pp = cur == CUR_POP;                            // lanes that still owe a pop from the previous trip
@@ -451,6 +470,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         pp = pp || (isn && !(hL || hR));
         RT_POP2(pp);
       }
+      RT_PRIO(0);
       RT_TICK(1);
     } else if (trip == 1) {
       // ================================================= PRIM step (closestHitList, HitHelpers.hs:11-16)
@@ -458,6 +478,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (STATS) st[STAT_IT_PRIM]++;
       RT_TICK(0);
       RT_MARK("PRIM_BEGIN");
+      RT_PRIO(RT_PRIO_PRIM);
 #pragma unroll
       for (int it = 0; it < PRIM_UNROLL; ++it) {
         const bool use_p = SPEC && pend != 0;               // the postponed leaf comes first: traversal order
@@ -541,6 +562,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         sp = lit_done ? 0 : sp;
         if (SPEC) pend = lit_done ? 0 : pend;
       }
+      RT_PRIO(0);
       RT_TICK(2);
     }
     asm volatile("" : "+s"(trip));
@@ -549,6 +571,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (STATS) st[STAT_IT_SHADE]++;
       RT_TICK(0);
       RT_MARK("SHADE_BEGIN");
+      RT_PRIO(RT_PRIO_SHADE);
       if (is_done) {                                         // (every sub-block re-reads the arguments it needs: RT_COLD_ARGS)
         double *r_ = rec;
         asm volatile("" : "+v"(r_) : : "memory");           // the record is re-read from memory, never carried in registers
@@ -733,6 +756,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         if (!need_finish) { RT_COLD_ARGS(); RT_BEGIN_QUERY(q_tmax); }
         RT_TICK_SH(11);
       }
+      RT_PRIO(0);
       RT_MARK("SHADE_END");
       RT_TICK(3);
       RT_MARK("REFILL_END");
