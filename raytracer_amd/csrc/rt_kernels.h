@@ -334,18 +334,24 @@ RT_DEV bool box_interval(const BoxRay<double> &r, const double *bx, double tmin,
 #define PLANE_MISS 0
 #define PLANE_HIT 1
 #define PLANE_LITERAL 2
-// A hit at distance t of a plane - a primitive that its own box does NOT contain - classified against the interval its
-// leaf receives.  bi: index of the leaf's FP64 box in plane_boxes, < 0 for a single-leaf root (the raw ray interval,
-// BVH.hs:121, Trace.hs:24).  (The leaf's box is a proper box inside all its ancestors' boxes, so their clipping adds nothing;
+// A hit at distance t of a primitive classified against the interval its reference leaf receives: planes, which their box does
+// NOT contain (Plane.hs:20), and spheres of positive radius, whose exact box c -+ r (Sphere.hs:20-22, no pad) the sphere touches
+// in six points - a ray that hits it there has t1 == the box's entry distance in exact arithmetic and one ulp below it in
+// FP64 about one time in three, and the reference then sees THROUGH the sphere (`contains interval t1`, Sphere.hs:26).
+// bi: index of the leaf's FP64 box in plane_boxes, < 0 for a single-leaf root (the raw ray interval, BVH.hs:121, Trace.hs:24).
+// (The leaf's box is a proper box inside all its ancestors' boxes and rounding is monotone, so their clipping adds nothing;
 // spheres of radius <= 0, for which that does not hold, go to literal_hit on every candidate hit: see the PRIM step.)
+// One evaluation of hitAABBInterval with an open upper end gives te = max(slab entries, tmin) and the box's OWN exit tx;
+// the reference enters the leaf iff te <= min(tx, tmax) (tmax = the closest hit so far) and accepts iff te <= t <= tmax -
+// with t <= tx an ordinary candidate, beyond it only through [minVal iSecond, t firstHit] (BVH.hs:137-138): literal_hit.
 RT_DEV int classify_in_leaf(long long bi, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double t) {
   if (bi < 0) return (t >= tmin && t <= tmax) ? PLANE_HIT : PLANE_MISS;
   BoxRay<double> br;
   make_boxray(br, ro, rd, 0.0f);
   double te, tx;
-  if (!box_interval(br, plane_boxes + 6 * bi, tmin, tmax, te, tx)) return PLANE_MISS;   // the leaf is not entered (or only behind a closer hit)
-  if (!(t >= te && t <= tmax)) return PLANE_MISS;              // `contains interval t` (tmax = the closest hit so far)
-  (void)box_interval(br, plane_boxes + 6 * bi, tmin, __builtin_huge_val(), te, tx);     // the box's own exit
+  if (!box_interval(br, plane_boxes + 6 * bi, tmin, __builtin_huge_val(), te, tx)) return PLANE_MISS;   // the leaf's box is missed
+  if (!(te <= tmax)) return PLANE_MISS;                        // ... or entered only behind a closer hit
+  if (!(t >= te && t <= tmax)) return PLANE_MISS;              // `contains interval t`
   return t <= tx ? PLANE_HIT : PLANE_LITERAL;
 }
 RT_DEV int hit_plane(const DPrim &P, const double *plane_boxes, d3 ro, d3 rd, double tmin, double tmax, double &tout) {

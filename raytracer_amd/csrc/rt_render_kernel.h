@@ -518,7 +518,25 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             // sphere of radius 0 is a point on the faces of its own box, where every hit is rounding noise.  Both are seen only
             // through the interval the reference's traversal hands their leaf (the chain of clipped ancestor intervals), so
             // a candidate hit settles the whole query with the literal walk.  d[6] < 0: the leaf is the root (raw interval).
-            if (h && !(P.d[3] > 0.0) && P.d[6] >= 0.0) { ps = PLANE_LITERAL; h = false; }
+            // A sphere of POSITIVE radius touches its exact box (no pad, unlike Triangle.hs:24-28): where it is hit at such a point
+            // t1 can fall an ulp outside the interval its leaf receives (Sphere.hs:26), so a candidate hit is classified against
+            // that interval like a plane's.
+            // Only a hit within rounding of a box face can fall outside: a hit point at least r / 1000 inside the sphere's own box on
+            // every axis (a box inside the leaf's, and rounding is monotone) is inside the leaf's slab interval by r / (1000 |d|),
+            // which is compared with a bound of 1e-12 x (the magnitudes that enter the slab distances and t1) - four orders above their
+            // rounding errors; such hits skip the exact re-test of the leaf's box (3 FP64 divisions), the others take it.
+            if (h) {
+              if (!(P.d[3] > 0.0)) { if (P.d[6] >= 0.0) { ps = PLANE_LITERAL; h = false; } }
+              else if (P.d[6] >= 0.0) {
+                const double r_ = P.d[3], m_ = 0.999 * r_;
+                const double qx = fabs((ro_.x + t * rd_.x) - P.d[0]), qy = fabs((ro_.y + t * rd_.y) - P.d[1]), qz = fabs((ro_.z + t * rd_.z) - P.d[2]);
+                const double mag = (fabs(ro_.x) + fabs(ro_.y) + fabs(ro_.z)) + (fabs(P.d[0]) + fabs(P.d[1]) + fabs(P.d[2])) + (r_ + t * (fabs(rd_.x) + fabs(rd_.y) + fabs(rd_.z)));
+                // (an axis under the parallel rule, |d| < 1e-8, is decided by the ORIGIN's position, BoundingBox.hs:21-22: exact path)
+                const bool deep = qx <= m_ && qy <= m_ && qz <= m_ && 0.001 * r_ > 1e-12 * mag &&
+                                  !(fabs(rd_.x) < 1e-7) && !(fabs(rd_.y) < 1e-7) && !(fabs(rd_.z) < 1e-7);
+                if (!deep) { ps = classify_in_leaf((long long)P.d[6], sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t); h = ps == PLANE_HIT; }
+              }
+            }
           } else if (isl && kind == RT_PRIM_PLANE) {
             if (STATS) st[STAT_PLANE]++;
             ps = hit_plane(P, sc.plane_boxes, ro_, rd_, RT_TMIN, best_t, t);

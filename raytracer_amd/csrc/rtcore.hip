@@ -89,9 +89,15 @@ int init_device(int device) {            // with `device` current; idempotent
   return RT_OK;
 }
 
+// Entry points that can be the first call of a process initialise the calling thread's current device - but ONLY when nothing
+// has been initialised yet: a group chosen by rt_init / rt_init_devices is never replaced implicitly (a call from a fresh OS
+// thread, whose current device is 0 whatever the group is, must not turn the group [2, 3] into [0]).
+std::vector<int> group_snapshot() {
+  std::lock_guard<std::mutex> g(g_init_mu);
+  return g_group;
+}
 int ensure_init() {
-  int device = 0;
-  if (hipGetDevice(&device) == hipSuccess && device >= 0 && device < RT_MAX_DEVICES && g_dev[device].ready) return RT_OK;
+  if (!group_snapshot().empty()) return RT_OK;
   return rt_init(-1);
 }
 
@@ -394,8 +400,10 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
       if (in_leaf[k]) { return fail(RT_ERR_INVALID, "primitive %ld belongs to two leaves", k); }
       in_leaf[k] = 1;
       const uint32_t kd = prims[k].kind & DPRIM_KIND_MASK;
-      if (kd == RT_PRIM_SPHERE) prims[k].d[6] = -1.0;                      // (only read for a radius <= 0)
-      if ((kd == RT_PRIM_PLANE || (kd == RT_PRIM_SPHERE && !(prims[k].d[3] > 0.0))) && i != 0) {   // primitives their own box does not contain; the root's own box is never tested (BVH.hs:123)
+      if (kd == RT_PRIM_SPHERE) prims[k].d[6] = -1.0;
+      // planes (their box does not contain them) and spheres (they touch their unpadded box; radius <= 0: inside-out / point boxes)
+      // are tested against the interval their leaf RECEIVES; the root's own box is never tested (BVH.hs:123)
+      if ((kd == RT_PRIM_PLANE || kd == RT_PRIM_SPHERE) && i != 0) {
         prims[k].d[6] = (double)(plane_boxes.size() / 6);
         for (int q = 0; q < 6; ++q) plane_boxes.push_back(d->node_bounds[6 * (size_t)i + q]);
       }
@@ -635,6 +643,7 @@ int rt_init(int device) {
   HIP_TRY(hipSetDevice(device));
   int rc = init_device(device);
   if (rc) return rc;
+  std::lock_guard<std::mutex> g(g_init_mu);
   g_group.assign(1, device);
   return RT_OK;
 }
@@ -663,13 +672,17 @@ int rt_init_devices(int32_t n_devices, const int32_t *devices) {
       }
     }
   }
+  std::lock_guard<std::mutex> g(g_init_mu);
   g_group = group;
   return RT_OK;
 }
 
-int rt_device_count(void) { return (int)g_group.size(); }
+int rt_device_count(void) { return (int)group_snapshot().size(); }
 
-void rt_shutdown(void) { g_group.clear(); }
+void rt_shutdown(void) {
+  std::lock_guard<std::mutex> g(g_init_mu);
+  g_group.clear();
+}
 
 void rt_scene_destroy(rt_scene *s) {
   if (!s) return;
@@ -688,7 +701,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
   HostScene hs;
   if ((rc = prepare_host_scene(d, hs))) return rc;
   auto *s = new rt_scene();
-  const std::vector<int> group = g_group.empty() ? std::vector<int>{0} : g_group;
+  const std::vector<int> group = group_snapshot();           // (non-empty after ensure_init)
+  if (group.empty()) return fail(RT_ERR_INVALID, "rt_shutdown ran concurrently with rt_scene_create");
   for (size_t i = group.size(); i-- > 0;) {                  // device 0 of the group last: it stays current
     Replica *r = nullptr;
     if (hipSetDevice(group[i]) != hipSuccess) { rt_scene_destroy(s); return fail(RT_ERR_HIP, "hipSetDevice(%d) failed", group[i]); }

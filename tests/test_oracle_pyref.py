@@ -69,3 +69,15 @@ def test_planes_outside_their_slab_box():
     check(two_object_scene(width=32, height=18, spp=1))
     check(two_object_scene(width=20, height=12, spp=2, max_bounces=3, antialiasing=True))
     check(random_plane_scene(5, n_tris=60, width=20, height=12, spp=1))
+
+
+def test_sphere_hit_where_it_touches_its_box():
+    """Sphere.hs:20-27 + BVH.hs:124-139: the centre ray's t1 is one ulp below the leaf's slab entry, so with
+    two leaves under an internal root both restatements see THROUGH the sphere there; with a single-leaf root both see it."""
+    from sphere_cases import two_sphere_scene
+    for lt, want in ((1, -1), (4, 0)):
+        spec = two_sphere_scene(lt)
+        (rad, col, rgb, ids), ref = both(spec)
+        assert ids[8, 16] == want and ref["prim_id"][8, 16] == want
+        check(spec)
+    check(two_sphere_scene(1, lights=True, max_bounces=3, width=17, height=9))

@@ -4,7 +4,7 @@ triangles, spheres (a few with negative or zero radius), planes of random point 
 glass / metal / emissive materials, point and directional lights, gradient / solid / LDR / HDR sky, thin lens, random
 leafThreshold / bvhMaxDepth / maxBounces, Russian roulette on some seeds; all three box_precision modes.
 Prints one line per seed; exit status 1 if any pixel's id differs or any radiance differs by more than 1e-12 (relative to
-max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme]"""
+max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme] [--axis]"""
 import os
 import sys
 
@@ -110,9 +110,59 @@ def scene(seed, big=False, extreme=False):
     return spec, rr
 
 
+def scene_axis(seed):
+    """Spheres hit where they TOUCH their own box.  Sphere.hs:20-22 boxes a sphere exactly (c -+ r, no pad), so
+    a ray along an axis through the centre has t1 == the box's entry distance in exact arithmetic, and in FP64 t1 falls one ulp
+    below it about one time in three: `contains interval t1` (Sphere.hs:26) then fails and the reference sees through the sphere
+    whenever its leaf is entered through an internal node.  Camera exactly on an axis through a sphere's centre, odd frame
+    dimensions (the centre pixel's ray has rayu = rayv = 0.5 exactly); every third seed the camera is moved sideways by the
+    radius, so that the centre ray is TANGENT to the sphere at an equator point and runs inside a face of its box."""
+    rng = np.random.default_rng(1_000_003 * 7 + seed)
+    names = ["matte", "metal", "glass", "lamp", None]
+    mats = [("matte", {"diffuseColor": list(rng.uniform(0.2, 0.9, 3))}),
+            ("metal", {"diffuseColor": [0.9, 0.9, 0.9], "shininess": 300.0}),
+            ("glass", {"diffuseColor": [1.0, 1.0, 1.0], "ior": float(rng.uniform(1.1, 1.8)), "transmission": 1.0}),
+            ("lamp", {"diffuseColor": [0.8, 0.8, 0.8], "emissionColor": list(rng.uniform(0.0, 3.0, 3))})]
+    n_sph = int(rng.integers(2, 9))
+    cfg, spheres = [], []
+    for _ in range(n_sph):
+        c = rng.uniform(-4, 4, 3)
+        r = float(rng.uniform(0.05, 1.2))
+        if rng.random() < 0.3:                                   # round numbers: exactly representable box faces
+            c, r = np.round(c * 4) / 4, float(np.round(r * 8) / 8 + 0.125)
+        spheres.append((c, r))
+        cfg.append(("sphere", [float(x) for x in c], r, names[int(rng.integers(0, 5))]))
+    if rng.random() < 0.5:                                       # a few triangles, so that leaves mix kinds
+        for _ in range(int(rng.integers(1, 4))):
+            v = rng.uniform(-5, 5, size=(3, 3))
+            cfg.append(("triangle", list(v[0]), list(v[1]), list(v[2]), names[int(rng.integers(0, 5))]))
+    c, r = spheres[int(rng.integers(0, n_sph))]
+    ax = int(rng.integers(0, 3))
+    e = np.zeros(3); e[ax] = float(rng.choice([-1.0, 1.0]))
+    dist = float(rng.uniform(2.0, 30.0))
+    side = np.zeros(3)
+    if seed % 3 == 2:                                            # grazing: the centre ray touches the sphere at an equator point
+        side[(ax + 1 + int(rng.integers(0, 2))) % 3] = float(rng.choice([-1.0, 1.0])) * r
+    lf, la = c + side - dist * e, c + side
+    lights = []
+    for _ in range(int(rng.integers(0, 3))):                     # lights on an axis through another sphere: shadow rays through touch points
+        c2, r2 = spheres[int(rng.integers(0, n_sph))]
+        e2 = np.zeros(3); e2[int(rng.integers(0, 3))] = float(rng.choice([-1.0, 1.0]))
+        lights.append({"tag": "PointLight", "position": list(c2 + e2 * float(rng.uniform(3, 12))), "intensity": list(rng.uniform(5, 60, 3))})
+    spec = scenes.SceneSpec(
+        name=f"axis{seed}", width=2 * int(rng.integers(8, 40)) + 1, height=2 * int(rng.integers(5, 24)) + 1, spp=int(rng.integers(1, 3)),
+        antialiasing=bool(rng.random() < 0.25), gamma=1.0, exposure=1.0,
+        background={"tag": "SolidColor", "color": list(rng.uniform(0, 1.5, 3))},
+        camera={"lookFrom": [float(x) for x in lf], "lookAt": [float(x) for x in la], "vUp": [0.0, 0.0, 1.0] if ax == 1 else [0.0, 1.0, 0.0],
+                "vfov": float(rng.uniform(5, 70)), "aperture": 0.0, "focusDist": 3.0},
+        max_bounces=int(rng.integers(1, 5)), bvh_max_depth=int(rng.choice([2, 6, 32])), leaf_threshold=int(rng.integers(1, 5)),
+        materials=mats, lights=lights, config_objects=cfg, seed=int(rng.integers(0, 2 ** 40)))
+    return spec, 0
+
+
 def main():
-    big, extreme = "--big" in sys.argv, "--extreme" in sys.argv
-    for f in ("--big", "--extreme"):
+    big, extreme, axis = "--big" in sys.argv, "--extreme" in sys.argv, "--axis" in sys.argv
+    for f in ("--big", "--extreme", "--axis"):
         if f in sys.argv:
             sys.argv.remove(f)
     if len(sys.argv) > 2 and sys.argv[1] == "--seeds":
@@ -121,7 +171,7 @@ def main():
         seeds = range(*((int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)))
     bad = 0
     for seed in seeds:
-        spec, rr = scene(seed, big, extreme)
+        spec, rr = scene_axis(seed) if axis else scene(seed, big, extreme)
         o = O.OracleScene(spec)
         ref = o.render(rr_start_bounce=rr, n_threads=min(16, os.cpu_count() or 8))
         o.close()
