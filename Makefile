@@ -24,9 +24,12 @@ oracle: oracle/_build/liboracle.so
 # -ffp-contract=off: the reference (GHC) forms no FMAs, and hit decisions at shared edges and vertices depend on the last bit
 # of t, u and v.  With contraction off the kernel's FP64 arithmetic rounds like the reference's (measured: radiance equal to
 # ~1e-16, no primitive-id mismatches); the FP32 box tests use explicit fmaf and are not affected.
+# RT_BUILD_ID: digest of the kernel sources + compile-time knobs, returned by rt_build_id(); counter records under profiles/
+# carry it so that bench.py can tell when they were taken on another kernel
 raytracer_amd/lib/librtcore.so: $(CORE_SRC) $(CORE_HDR)
 	@mkdir -p raytracer_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(KERNEL_DEFS) $(CORE_SRC) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(KERNEL_DEFS) \
+	    -DRT_BUILD_ID=\"$$( (cat $(CORE_SRC) $(sort $(CORE_HDR)); echo "$(RT_MIN_WAVES) $(KERNEL_DEFS)") | sha256sum | cut -c1-16)\" $(CORE_SRC) -o $@
 
 # -ffp-contract=off: the BVH builder's sort keys must round exactly like the reference's doubles
 raytracer_amd/lib/librthost.so: $(HOST_SRC) $(HOST_HDR)

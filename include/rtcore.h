@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3
+#define RT_ABI_VERSION 4
 
 /* ---- status codes (error convention replaces `error`/exitFailure, app/Main.hs:24-26) */
 #define RT_OK                 0
@@ -186,7 +186,7 @@ typedef struct rt_scene rt_scene;
 int  rt_init(int device);
 /* Select a GROUP of devices for a single-process host (the reference is one process that calls createPPM once,
  * app/Main.hs:53): scenes created afterwards are replicated on every device of the group and ONE blocking rt_render call
- * fans the frame out over them - tile (tx,ty) to device (tx+ty) mod n, one host thread and one stream per device, the
+ * fans the frame out over them - tile (tx,ty) to device (tx+ty) mod n (see rt_tile_skew), one host thread and one stream per device, the
  * packed tiles brought to devices[0] as peer copies over xGMI - replacing the 24 green threads and the row TQueue of
  * app/Rendering/ImageGenerator.hs:37,64-94.  n_devices = 0 with devices = NULL selects every visible device.  Entries may
  * repeat ("virtual devices": how the tests exercise the fan-out on one GPU).  The frame is bit-identical for every n. */
@@ -195,6 +195,13 @@ int  rt_device_count(void);   /* size of the current group (1 after rt_init) */
 void rt_shutdown(void);
 const char *rt_last_error(void);
 int  rt_abi_version(void);
+/* Measurement hooks (no counterpart in the reference).  rt_build_id: a digest of the kernel sources and compile-time knobs
+ * this library was built from (Makefile) - committed counter records (profiles/pmc_traffic.json) carry it, so that bench.py
+ * can tell a record taken on another kernel (stale) from one taken on the library it loaded.  rt_kernel_name: the
+ * k_render_tiles instantiation a render of `scene` with `params` launches, spelt as rocprofv3 prints it (it depends on
+ * box_precision, collect_stats, rr_start_bounce and on whether the scene has the core's own tree). */
+const char *rt_build_id(void);
+int  rt_kernel_name(rt_scene *scene, const rt_params *params, char *buf, int32_t cap);
 
 /* Copies the descriptor's arrays to HBM in the kernels' layout; borrows nothing after return. */
 int  rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
@@ -220,6 +227,9 @@ int  rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params,
  * A rank's tiles, in increasing ty*tiles_x+tx order, are its "local tiles"; the packed
  * buffers below hold 64 pixel slots per local tile (slot = local_tile*64 + (py&7)*8 + (px&7)). */
 int  rt_tile_count(int32_t width, int32_t height, int32_t rank, int32_t world);
+/* (Experiment knob: the environment variable RT_TILE_SKEW = k, read ONCE per process, changes the map to (tx + k*ty) mod world
+ * for every entry point of the library; rt_tile_skew returns the value in force, 1 by default.) */
+int  rt_tile_skew(void);
 /* tiles: out, rt_tile_count() entries of ty*tiles_x+tx */
 int  rt_tile_list(int32_t width, int32_t height, int32_t rank, int32_t world, int32_t *tiles);
 

@@ -78,7 +78,7 @@ foreign import ccall safe "rt_abi_version" c_rt_abi_version :: IO CInt
 
 -- BEGIN-ABI-LAYOUT  (x86-64 SysV; generated from tools/abi_layout.c, verified by tests/test_haskell_offsets.py)
 rt_abi_version_expected :: Int
-rt_abi_version_expected = 3
+rt_abi_version_expected = 4
 
 sizeof_rt_material, off_rt_material_id, off_rt_material_flags, off_rt_material_diffuse, off_rt_material_emission, off_rt_material_shininess, off_rt_material_ior, off_rt_material_transmission :: Int
 sizeof_rt_material = 80

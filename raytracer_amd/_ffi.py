@@ -87,6 +87,9 @@ RTCORE_SYMBOLS = {
     "rt_shutdown": (None, []),
     "rt_last_error": (C.c_char_p, []),
     "rt_abi_version": (C.c_int, []),
+    "rt_build_id": (C.c_char_p, []),
+    "rt_kernel_name": (C.c_int, [C.c_void_p, C.POINTER(rt_params), C.c_char_p, C.c_int32]),
+    "rt_tile_skew": (C.c_int, []),
     "rt_scene_create": (C.c_int, [C.POINTER(rt_scene_desc), C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(rt_output), C.POINTER(rt_stats)]),

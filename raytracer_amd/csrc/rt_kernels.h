@@ -62,6 +62,7 @@ struct KFrame {
   double *samples;             // [n_items][3] radiance of every path of this launch, summed per pixel by k_resolve
   int32_t rr_start;            // 0: off (the reference); k > 0: Russian roulette once a path has made k bounces (opt-in extension)
   int32_t lit_row;             // first row of literal_hit's per-lane stack within a wave's fscratch block (scenes with planes), else -1
+  int32_t exact_row;           // BT = double: first of stack_depth rows holding the stacked children's exact FP64 entry distances
   unsigned long long *dbg;     // experiment builds (-DRT_TIMERS) only: 4 words per wave, see the end of k_render_tiles
 };
 
@@ -187,7 +188,11 @@ RT_COLD d3 background(const KScene &sc, d3 dir) {
       return mk3(p[k] / 255.0, p[k + 1] / 255.0, p[k + 2] / 255.0);
     }
     const float *p = (const float *)sc.sky;
+#ifdef RT_SKY_NT
+    return mk3((double)__builtin_nontemporal_load(p + k), (double)__builtin_nontemporal_load(p + k + 1), (double)__builtin_nontemporal_load(p + k + 2));
+#else
     return mk3((double)p[k], (double)p[k + 1], (double)p[k + 2]);
+#endif
   }
   if (sc.bg_kind == RT_BG_SOLID) return ld3(sc.bg1);                // ImageGenerator.hs:131
   d3 unit = normalize3(dir);                                        // :133

@@ -198,6 +198,10 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
   double *lrec = (double *)(stack + RT_STACK_LDS * 64);    // this lane's hot record rows (LDS)
   double *rec = fr.fscratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * fr.scratch_rows * 64 + lane;
   uint2 *ovf = (uint2 *)(rec + PR_ROWS * 64);              // stack entries RT_STACK_LDS, RT_STACK_LDS + 1, ... of this lane
+  // box_precision = 1 (BT = double) is the LITERAL walk: a stacked child is entered iff its exact FP64 entry distance is not beyond
+  // the closest hit so far (the reference's [minVal iSecond, t firstHit] is non-empty, BVH.hs:137-138).  The 8-byte stack entry
+  // holds that distance rounded down to FP32 (a conservative cull); the exact double goes to a row of its own in global memory.
+  double *xst = rec + (size_t)(sizeof(BT) == 8 ? fr.exact_row : 0) * 64;
   const DNode<BT> *nodes = (const DNode<BT> *)sc.nodes;
   const int top_nodes_v = fr.top_nodes;
   const double inf = __builtin_huge_val();
@@ -258,7 +262,8 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         if ((p_) && spn_ >= RT_STACK_LDS) e_ = ovf[(spn_ - RT_STACK_LDS) * 64];      \
       }                                                                              \
       const bool empty_ = sp == 0;                                                   \
-      const bool culled_ = cull_entry(__uint_as_float(e_.y), tmaxb);                 \
+      bool culled_ = cull_entry(__uint_as_float(e_.y), tmaxb);                       \
+      if constexpr (sizeof(BT) == 8) { if ((p_) && spn_ >= 0) culled_ = xst[spn_ * 64] > best_t; }   \
       cur = (p_) ? (empty_ ? CUR_DONE : (culled_ ? cur : (int)e_.x)) : cur;          \
       sp = ((p_) && !empty_) ? spn_ : sp;                                            \
       p_ = (p_) && !empty_ && culled_;                                               \
@@ -285,7 +290,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
       if (RR) T = rec[PR_S * 64] * T;       // (extension) the roulette weight of this depth
       const d3 R = clamp3(T + fa, fl, fh);
       double *o_ = fr.samples + 3 * (size_t)item;
+      // written once, read once by k_resolve after the launch: non-temporal, so that the stream (5 GB on C4, 51 GB on C5) does not
+      // push nodes out of L2 (C4 kernel 41.36 -> 41.12 ms, C5 516.8 -> 512.1; profiles/r03_ab_nt.txt.  The same hint on the sky
+      // texel loads costs 1.5 ms on C4: neighbouring samples re-read the same texels, and they should stay cached)
+#ifndef RT_SAMPLE_TEMPORAL
+      __builtin_nontemporal_store(R.x, o_); __builtin_nontemporal_store(R.y, o_ + 1); __builtin_nontemporal_store(R.z, o_ + 2);
+#else
       o_[0] = R.x; o_[1] = R.y; o_[2] = R.z;
+#endif
       cur = CUR_IDLE;
     }
   };
@@ -464,6 +476,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           if constexpr (sizeof(BT) == 8) tsf = __double2float_rd((double)ts); else tsf = (float)ts;
           const uint2 ent = make_uint2((uint32_t)(lf ? refR : refL), __float_as_uint(tsf));
           if (sp < RT_STACK_LDS) stack[sp * 64] = ent; else ovf[(sp - RT_STACK_LDS) * 64] = ent;
+          if constexpr (sizeof(BT) == 8) xst[sp * 64] = (double)ts;
           ++sp;
         }
         cur = (hL || hR) ? ((hL && (lf || !hR)) ? refL : refR) : cur;
@@ -549,9 +562,13 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
               // query is answered by the literal walk of the reference's tree and this lane's traversal ends here.
               RT_COLD_ARGS();
               if (STATS) st[STAT_LITERAL]++;
+              // (box_precision = 1 does not stop a shadow query at its first hit: one that already holds a hit is blocked whatever
+              // follows.  The FP32-box kernels never get here with a hit - and this form keeps 9 VGPR spills out of their PRIM body.)
+              bool ask = true;
+              if constexpr (sizeof(BT) == 8) ask = !(li >= 0 && best >= 0);
               const LitHit lh = literal_hit((const DNode<double> *)sc.ref_nodes64, sc.prims, sc.ref_root_ref, rec + (size_t)fr.lit_row * 64,
                                             ro_.x, ro_.y, ro_.z, rd_.x, rd_.y, rd_.z, RT_TMIN, li >= 0 ? best_t : RT_TMAX);
-              best = lh.best; best_t = lh.t; tmaxb = tmax_for_boxes<BT>(lh.t);
+              if (ask) { best = lh.best; best_t = lh.t; tmaxb = tmax_for_boxes<BT>(lh.t); }
               lit_done = true;
             }
           }
@@ -570,7 +587,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
         best = h ? (FAST ? P.mat : pi) : best;               // FAST: the slot holds the primitive's index in the reference's order
         tmaxb = h ? tmax_for_boxes<BT>(t) : tmaxb;
-        const bool blocked = h && li >= 0;                   // shadow ray: any hit blocks (Light.hs:30-32)
+        // shadow ray: any hit blocks (Light.hs:30-32 only tests Just / Nothing), so the query stops at the first one - except in
+        // box_precision = 1, the literal walk, which like the reference runs every shadow query as a full closest-hit query
+        const bool blocked = h && li >= 0 && sizeof(BT) == 4;
         const bool last = (P.kind & DPRIM_LAST) != 0u;
         if (SPEC) pend = use_p ? ((blocked || last) ? 0 : pend - 1) : (blocked ? 0 : pend);
         cur = isl ? (blocked ? CUR_DONE : ((last || use_p) ? cur : cur - 1)) : cur;   // cur - 1 == ~(pi + 1)

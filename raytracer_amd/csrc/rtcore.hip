@@ -632,6 +632,11 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char *rt_build_id(void) { return RT_BUILD_ID; }
+int rt_tile_skew(void) { return tile_skew(); }
 const char *rt_last_error(void) { return g_err.c_str(); }
 
 int rt_init(int device) {
@@ -797,6 +802,8 @@ static int launch_kernel(Replica *s, Workspace &ws, const KFrame &fr_in, hipStre
     fr.lit_row = fr.scratch_rows;
     fr.scratch_rows += 3 * (std::max(1, s->depth) + 1);
   }
+  fr.exact_row = 0;
+  if (sizeof(BT) == 8) { fr.exact_row = fr.scratch_rows; fr.scratch_rows += fr.stack_depth; }
   int wpb = RT_BLOCK_THREADS / 64;
   if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env)));   // experiment knob
   const size_t lds_cu = 160 * 1024 / RT_BLOCKS_PER_CU;       // LDS one workgroup may use
@@ -954,6 +961,16 @@ static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const 
   if (mode == 1) return st ? launch_kernel<double, true, false>(s, ws, fr, stream) : launch_kernel<double, false, false>(s, ws, fr, stream);
   if (mode == 0 && s->has_fast) return st ? launch_kernel<float, true, true>(s, ws, fr, stream) : launch_kernel<float, false, true>(s, ws, fr, stream);
   return st ? launch_kernel<float, true, false>(s, ws, fr, stream) : launch_kernel<float, false, false>(s, ws, fr, stream);
+}
+
+// Template arguments of the k_render_tiles instantiation launch_render picks for (scene, params), as rocprofv3 prints them.
+static std::string kernel_args_of(const Replica *s, const rt_params *p) {
+  const int mode = s->inverted_boxes ? 1 : p->box_precision;
+  const bool fast = mode == 0 && s->has_fast;
+  char buf[64];
+  snprintf(buf, sizeof buf, "%s, %s, %s, %s", mode == 1 ? "double" : "float", p->collect_stats ? "true" : "false",
+           fast ? "true" : "false", p->rr_start_bounce > 0 ? "true" : "false");
+  return buf;
 }
 
 static int read_stats(const Workspace &ws, rt_stats *st) {   // ADDS this workspace's counters to *st
@@ -1239,6 +1256,14 @@ int rt_render_tiles_device_noalloc(rt_scene *s, const rt_camera *cam, const rt_p
   // (launch_kernel), the statistics when they are collected, the tile list is rewritten, records and samples are
   // written before they are read
   return render_tiles_common(s, ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, stream, stats);
+}
+
+int rt_kernel_name(rt_scene *sc, const rt_params *p, char *buf, int32_t cap) {
+  if (!sc || sc->rep.empty() || !p || !buf || cap <= 0) return fail(RT_ERR_INVALID, "null argument");
+  const std::string a = "k_render_tiles<" + kernel_args_of(sc->rep[0], p) + ">";
+  if ((size_t)cap <= a.size()) return fail(RT_ERR_INVALID, "buffer of %d bytes too small for the kernel name", (int)cap);
+  std::memcpy(buf, a.c_str(), a.size() + 1);
+  return RT_OK;
 }
 
 int rt_kernel_times(rt_scene *sc, double *sum_ms, int32_t *n_launches) {

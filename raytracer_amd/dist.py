@@ -12,7 +12,6 @@ every world size.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -30,8 +29,10 @@ def tiles_y(height):
 
 
 def tile_skew() -> int:
-    """1 unless RT_TILE_SKEW says otherwise (the experiment knob librtcore reads too, tools/rank_timing.py)."""
-    return max(1, int(os.environ.get("RT_TILE_SKEW", "1") or 1))
+    """The skew of the tile -> rank map IN FORCE in librtcore (1 unless the experiment knob RT_TILE_SKEW said otherwise when
+    the library first read it): asked of the library, so that this module's tile ownership and the device tile lists can
+    never disagree, whatever happens to the environment variable after the first call."""
+    return int(F.core().rt_tile_skew())
 
 
 def tile_owner(tx, ty, world):

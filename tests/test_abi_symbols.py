@@ -22,7 +22,8 @@ def test_rtcore_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(F.LIB_DIR, "librtcore.so"))
     for n in names:
         getattr(lib, n)
-    assert F.core().rt_abi_version() == 3
+    assert F.core().rt_abi_version() == 4
+    assert len(F.core().rt_build_id()) == 16 and F.core().rt_tile_skew() == 1
 
 
 def test_rthost_exports_every_declared_symbol():

@@ -170,20 +170,34 @@ def test_edge_cases(need_gpu):
 
 
 def test_ray_counters_match_oracle(need_gpu):
-    spec = scenes.c3_blob988(width=160, height=90, spp=2)
-    g = api.GpuScene(spec)
-    res, st = g.render(collect_stats=1, box_precision=1)
-    g.close()
-    o = O.OracleScene(spec)
-    ref, cnt = o.render(counters=True)
-    o.close()
-    assert np.abs(res["radiance"] - ref["radiance"]).max() <= TOL
-    # ray counts are path-structure counts: equal, since no path diverges
-    assert st.rays_closest == cnt["rays_closest"] and st.rays_shadow == cnt["rays_shadow"] and st.shaded_hits == cnt["shaded_hits"]
-    # the kernel culls stacked nodes the reference still enters with an empty interval
-    assert st.nodes_visited <= cnt["nodes_literal"]
-    assert st.nodes_visited >= 0.5 * cnt["nodes_nonempty"]
-    assert st.paths == 160 * 90 * 2
+    """box_precision = 1 is the LITERAL walk: the kernel's traversal work EQUALS the reference's.  A stacked child is entered iff
+    its exact FP64 entry distance is not beyond the closest hit so far - the reference's [minVal iSecond, t firstHit] is
+    non-empty (BVH.hs:137-138; the oracle's *_nonempty counters) - and shadow queries run to the end like the reference's
+    (Light.hs:30,42 call the same closest-hit `hit`).  The default mode's own tree does less of everything."""
+    cases = [scenes.c3_blob988(width=160, height=90, spp=2)]
+    spec = scenes.c2_spheres(width=120, height=68, spp=2)                      # spheres + a plane inside its slab box, mixed leaves
+    spec.config_objects.append(("plane", [0.0, 0.0005, 0.0], [0.0, 1.0, 0.0], "blue"))
+    spec.leaf_threshold = 2
+    cases.append(spec)
+    for spec in cases:
+        g = api.GpuScene(spec)
+        res, st = g.render(collect_stats=1, box_precision=1)
+        res0, st0 = g.render(collect_stats=1, box_precision=0)
+        g.close()
+        o = O.OracleScene(spec)
+        ref, cnt = o.render(counters=True)
+        o.close()
+        assert np.abs(res["radiance"] - ref["radiance"]).max() <= TOL
+        # ray counts are path-structure counts: equal, since no path diverges
+        assert st.rays_closest == cnt["rays_closest"] and st.rays_shadow == cnt["rays_shadow"] and st.shaded_hits == cnt["shaded_hits"]
+        assert st.rays_literal == 0                                           # (a query answered by literal_hit is not counted node by node)
+        assert st.nodes_visited == cnt["nodes_nonempty"], (st.nodes_visited, cnt["nodes_nonempty"], cnt["nodes_literal"])
+        assert st.tri_tests == cnt["tri_tests_nonempty"], (st.tri_tests, cnt["tri_tests_nonempty"])
+        assert st.sphere_tests == cnt["sphere_tests_nonempty"] and st.plane_tests == cnt["plane_tests_nonempty"]
+        assert st.paths == spec.width * spec.height * spec.spp
+        # the timed mode: the same paths (shadow queries towards lights a surface faces away from are skipped and counted), less work
+        assert st0.rays_closest == st.rays_closest and st0.rays_shadow + st0.rays_shadow_culled == st.rays_shadow
+        assert st0.nodes_visited < st.nodes_visited
 
 
 def test_error_paths(need_gpu):
