@@ -807,7 +807,10 @@ static int launch_kernel(Replica *s, Workspace &ws, const KFrame &fr_in, hipStre
   int wpb = RT_BLOCK_THREADS / 64;
   if (const char *env = getenv("RT_WAVES_PER_BLOCK")) wpb = std::max(4, std::min(wpb, atoi(env)));   // experiment knob
   const size_t lds_cu = 160 * 1024 / RT_BLOCKS_PER_CU;       // LDS one workgroup may use
-  while (wpb > 4 && (size_t)wpb * stack_bytes > lds_cu - 6 * 1024) --wpb;
+#ifndef RT_LDS_RESERVE
+#define RT_LDS_RESERVE (6 * 1024)
+#endif
+  while (wpb > 4 && (size_t)wpb * stack_bytes > lds_cu - RT_LDS_RESERVE) --wpb;
   const int threads = wpb * 64;
   const size_t lds_waves = (size_t)wpb * stack_bytes;
   fr.top_nodes = 0;
