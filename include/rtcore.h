@@ -243,6 +243,12 @@ int  rt_render_tiles_device(rt_scene *scene, const rt_camera *cam, const rt_para
                             void *d_color, void *d_radiance, void *d_prim_id,
                             void *stream, rt_stats *stats);
 
+/* The same share of the frame as the 8-BIT tiles only (packed, 3 bytes per slot): k_resolve applies showPixel's
+ * quantisation (app/Rendering/RenderWorker.hs:108-109, per value) in the pass that averages the samples, so no colour
+ * buffer and no quantise launch exist on this path, and 3 bytes per pixel are what the gather moves.  d_rgb8: 3*64*ntiles bytes. */
+int  rt_render_tiles_rgb8_device(rt_scene *scene, const rt_camera *cam, const rt_params *params,
+                                 int32_t rank, int32_t world, void *d_rgb8, void *stream, rt_stats *stats);
+
 /* rt_render_tiles_device for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results to the bit; but the launch
  * workspace (chunk counter, statistics, tile list, path records, per-path radiance) is a 128-MiB static device array
@@ -273,6 +279,12 @@ int  rt_untile_device(int32_t width, int32_t height, int32_t rank, int32_t world
  * quantised per rank with rt_quantize_device (3 bytes per pixel over xGMI instead of 24). */
 int  rt_untile_bytes_device(int32_t width, int32_t height, int32_t rank, int32_t world,
                             const void *d_packed, void *d_image, int32_t n_bytes, void *stream);
+
+/* The gathered packed buffers of ALL ranks - rank r's slots start at d_packed_all + r * rank_stride_bytes, n_bytes per slot -
+ * scattered into the row-major device image of n_bytes*W*H bytes in ONE launch (rank 0 after the gather: one launch instead
+ * of `world`). */
+int  rt_untile_all_bytes_device(int32_t width, int32_t height, int32_t world, const void *d_packed_all, int64_t rank_stride_bytes,
+                                void *d_image, int32_t n_bytes, void *stream);
 
 /* Device image of 3*W*H doubles (color) -> 3*W*H uint8 (showPixel quantisation), on `stream`. */
 int  rt_quantize_device(const void *d_color, void *d_rgb8, int64_t n_values, void *stream);

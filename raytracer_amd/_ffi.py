@@ -99,6 +99,9 @@ RTCORE_SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]),
     "rt_render_tiles_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, C.c_int32,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]),
+    "rt_render_tiles_rgb8_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.POINTER(rt_stats)]),
+    "rt_untile_all_bytes_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "rt_init_devices": (C.c_int, [C.c_int32, c_int32_p]),
     "rt_device_count": (C.c_int, []),
     "rt_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

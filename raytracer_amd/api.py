@@ -211,12 +211,19 @@ class GpuScene:
         return ms.value, n.value
 
     def render_tiles_device(self, rank, world, d_color=0, d_radiance=0, d_prim_id=0, stream=0, camera=None, noalloc=False,
-                            **param_over):
+                            d_rgb8=0, **param_over):
         """rt_render_tiles_device: this rank's tiles into device buffers (raw pointers), asynchronous.
-        noalloc=True: rt_render_tiles_device_noalloc, the variant whose workspace is the library's static device array."""
+        noalloc=True: rt_render_tiles_device_noalloc, the variant whose workspace is the library's static device array.
+        d_rgb8 (alone): rt_render_tiles_rgb8_device, the packed 8-bit tiles quantised in the resolve pass."""
         p = make_params(self.spec, **param_over)
         st = F.rt_stats()
         cam = camera if camera is not None else self.camera
+        if d_rgb8:
+            if d_color or d_radiance or d_prim_id or noalloc:
+                raise ValueError("d_rgb8 is its own entry point: no other output, no noalloc")
+            F.check(F.core().rt_render_tiles_rgb8_device(self._h, C.byref(cam), C.byref(p), rank, world, C.c_void_p(d_rgb8),
+                                                         C.c_void_p(stream or None), C.byref(st)))
+            return st
         fn = F.core().rt_render_tiles_device_noalloc if noalloc else F.core().rt_render_tiles_device
         F.check(fn(self._h, C.byref(cam), C.byref(p), rank, world,
                    C.c_void_p(d_color or None), C.c_void_p(d_radiance or None),

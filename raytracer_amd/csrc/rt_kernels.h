@@ -48,6 +48,7 @@ struct KFrame {
   int32_t n_tiles, tiles_x;
   int32_t packed;              // 1: outputs indexed by local_tile*64+position ; 0: row-major full frame
   double *out_color, *out_radiance;
+  uint8_t *out_rgb8;           // the 8-bit frame (showPixel, RenderWorker.hs:108-109), written by k_resolve in the same pass
   int32_t *out_primid;
   uint32_t *tile_counter;      // hands out chunks of items
   unsigned long long *stats;   // STAT_COUNT counters, see STAT_*
@@ -454,6 +455,13 @@ RT_DEV unsigned long long wave_sum(unsigned long long v) {
 // (toneMap / gammaCorrect, Trace.hs:96-105).  A pixel's samples are spp x 24 contiguous bytes, a tile's 64 pixels one
 // contiguous region: the wave reads it RS_T samples at a time with all lanes on consecutive addresses (three 192-B runs per
 // instruction instead of 64 scattered 8-B reads), stages the sub-block in LDS and each lane then adds its own pixel's run.
+// showPixel's quantisation, RenderWorker.hs:108-109: truncate (c * 255.999); the reference neither clamps nor handles NaN
+// (its `show` would print the out-of-range integer): clamped to 0..255 here, NaN -> 0
+RT_DEV uint8_t quantize8(double c) {
+  double v = trunc(c * 255.999);
+  v = v != v ? 0.0 : (v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v));
+  return (uint8_t)v;
+}
 #define RS_T 8                      // samples per staged sub-block
 #define RS_ROW (3 * RS_T + 1)       // doubles per pixel row in LDS (+1: lanes on different banks)
 #define RS_WAVES 4
@@ -491,10 +499,14 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_resolve(const KFrame fr) {
   const d3 avg = mk3(inv * sx, inv * sy, inv * sz);                    // RenderWorker.hs:114
   const size_t o = 3 * (fr.packed ? (size_t)gt * 64 + pos : (size_t)py * fr.W + px);
   if (fr.out_radiance) { fr.out_radiance[o] = avg.x; fr.out_radiance[o + 1] = avg.y; fr.out_radiance[o + 2] = avg.z; }
-  if (fr.out_color) {
+  if (fr.out_color || fr.out_rgb8) {
     const double e = fr.exposure;
     const double tc[3] = {avg.x * e / (avg.x * e + 1), avg.y * e / (avg.y * e + 1), avg.z * e / (avg.z * e + 1)};   // Trace.hs:96-101
-    for (int c = 0; c < 3; ++c) fr.out_color[o + c] = pow_gamma(tc[c], fr.gamma);                                 // Trace.hs:103-105
+    for (int c = 0; c < 3; ++c) {
+      const double col = pow_gamma(tc[c], fr.gamma);                                                              // Trace.hs:103-105
+      if (fr.out_color) fr.out_color[o + c] = col;
+      if (fr.out_rgb8) fr.out_rgb8[o + c] = quantize8(col);                                                       // RenderWorker.hs:108-109
+    }
   }
 }
 
@@ -541,7 +553,36 @@ __global__ void k_untile_bytes(const int32_t *tiles, int n_tiles, int tiles_x, i
 __global__ void k_quantize(const double *color, uint8_t *rgb8, long long n) {       // showPixel, RenderWorker.hs:108-109
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double v = trunc(color[i] * 255.999);
-  v = v != v ? 0.0 : (v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v));
-  rgb8[i] = (uint8_t)v;
+  rgb8[i] = quantize8(color[i]);
+}
+
+// Per (rank, tile row): how many tiles of that rank lie in the rows above - the index of the row's first tile in the rank's list.
+__global__ void k_make_row_base(int tiles_x, int tiles_y, int world, int skew, int32_t *row_base) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= world * tiles_y) return;
+  const int rank = i / tiles_y, y = i - rank * tiles_y;
+  int base = 0;
+  for (int q = 0; q < y; ++q) base += tiles_in_row(tiles_x, q, rank, world, skew);
+  row_base[i] = base;
+}
+// The packed tiles of ALL ranks (rank r's slots at packed + r * rank_stride bytes) scattered into the row-major frame in one
+// launch: one thread per pixel finds its owner rank, its tile's place in that rank's list and its slot (writes are coalesced).
+__global__ void k_untile_all(const int32_t *row_base, int tiles_x, int tiles_y, int world, int skew, int W, int H, int n_bytes,
+                             size_t rank_stride, const uint8_t *packed, uint8_t *image) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)W * H) return;
+  const int py = (int)(i / (size_t)W), px = (int)(i - (size_t)py * W);
+  const int tx = px >> 3, ty = py >> 3;
+  const int rank = (int)(((long long)tx + (long long)skew * ty) % world);
+  const int lt = row_base[rank * tiles_y + ty] + (tx - tile_first_x(ty, rank, world, skew)) / world;
+  const size_t slot = (size_t)lt * 64 + (size_t)((py & 7) * 8 + (px & 7));
+  const uint8_t *src = packed + (size_t)rank * rank_stride + slot * n_bytes;
+  uint8_t *dst = image + i * n_bytes;
+  if ((n_bytes & 7) == 0 && (((size_t)src | (size_t)dst) & 7) == 0) {
+    for (int c = 0; c < n_bytes; c += 8) *(unsigned long long *)(dst + c) = *(const unsigned long long *)(src + c);
+  } else if ((n_bytes & 3) == 0 && (((size_t)src | (size_t)dst) & 3) == 0) {
+    for (int c = 0; c < n_bytes; c += 4) *(uint32_t *)(dst + c) = *(const uint32_t *)(src + c);
+  } else {
+    for (int c = 0; c < n_bytes; ++c) dst[c] = src[c];
+  }
 }

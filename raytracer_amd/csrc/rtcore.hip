@@ -205,9 +205,14 @@ struct Replica {
   double *p_color = nullptr, *p_radiance = nullptr;
   int32_t *p_primid = nullptr;
   uint8_t *p_rgb8 = nullptr;
-  double *g_color = nullptr, *g_radiance = nullptr;     // on the group's device 0 (for replica 0 they alias the p_ buffers)
-  int32_t *g_primid = nullptr;
+  double *g_color = nullptr, *g_radiance = nullptr;     // where they land on the group's device 0: slices of rep[0]'s gather areas
+  int32_t *g_primid = nullptr;                          // (replica 0 renders straight into its slices: its p_ pointers alias them)
   uint8_t *g_rgb8 = nullptr;
+  // replica 0 only: the gather areas, n replicas x cap_slots slots each, contiguous so that ONE k_untile_all launch scatters them
+  double *G_color = nullptr, *G_radiance = nullptr;
+  int32_t *G_primid = nullptr;
+  uint8_t *G_rgb8 = nullptr;
+  int G_n = 0;
   hipStream_t stream = nullptr;         // this replica's stream in a device group
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // HIP event pairs around the k_render_tiles launches since the last rt_kernel_times call (measurement hook)
@@ -228,11 +233,8 @@ static void replica_destroy(Replica *s) {
   (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky); (void)hipFree(s->d_sky_u_tab); (void)hipFree(s->d_sky_v_tab);
   (void)hipFree(s->ws.counter); (void)hipFree(s->ws.stats); (void)hipFree(s->ws.fscratch); (void)hipFree(s->ws.samples); (void)hipFree(s->ws.tiles);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
-  (void)hipFree(s->p_color); (void)hipFree(s->p_radiance); (void)hipFree(s->p_primid); (void)hipFree(s->p_rgb8);
-  if (s->g_color != s->p_color) (void)hipFree(s->g_color);
-  if (s->g_radiance != s->p_radiance) (void)hipFree(s->g_radiance);
-  if (s->g_primid != s->p_primid) (void)hipFree(s->g_primid);
-  if (s->g_rgb8 != s->p_rgb8) (void)hipFree(s->g_rgb8);
+  if (s->p_color != s->g_color) { (void)hipFree(s->p_color); (void)hipFree(s->p_radiance); (void)hipFree(s->p_primid); (void)hipFree(s->p_rgb8); }
+  (void)hipFree(s->G_color); (void)hipFree(s->G_radiance); (void)hipFree(s->G_primid); (void)hipFree(s->G_rgb8);
   for (hipEvent_t e : s->kt_events) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -931,7 +933,7 @@ static int launch_kernel(Replica *s, Workspace &ws, const KFrame &fr_in, hipStre
 }
 
 static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const rt_params *p, int rank, int world, bool packed,
-                         double *d_color, double *d_radiance, int32_t *d_primid, hipStream_t stream) {
+                         double *d_color, double *d_radiance, int32_t *d_primid, uint8_t *d_rgb8, hipStream_t stream) {
   int rc;
   KFrame fr{};
   fr.cam = *cam;
@@ -947,7 +949,7 @@ static int launch_render(Replica *s, Workspace &ws, const rt_camera *cam, const 
     fr.tiles = nullptr; fr.n_tiles = fr.tiles_x * tiles_y_of(p->height);
   }
   fr.packed = packed ? 1 : 0;
-  fr.out_color = d_color; fr.out_radiance = d_radiance; fr.out_primid = d_primid;
+  fr.out_color = d_color; fr.out_radiance = d_radiance; fr.out_primid = d_primid; fr.out_rgb8 = d_rgb8;
   if (fr.n_tiles == 0) return RT_OK;
 #ifdef RT_TIMERS
   const bool st = false;                                    // experiment build: collect_stats times the bodies of the TIMED variant
@@ -1034,6 +1036,34 @@ static int untile_launch(int W, int H, int rank, int world, const void *d_packed
   return RT_OK;
 }
 
+// per (device, W, H, world): k_make_row_base's table for k_untile_all, created once and kept
+struct RowBaseEntry { int device, W, H, world; int32_t *d_base; };
+static std::vector<RowBaseEntry> g_rowbase_cache;
+static int untile_all_launch(int W, int H, int world, const void *d_packed_all, size_t rank_stride_bytes, void *d_image, int n_bytes, hipStream_t stream) {
+  if (W <= 0 || H <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const int tx = tiles_x_of(W), ty = tiles_y_of(H);
+  int32_t *d_base = nullptr;
+  {
+    std::lock_guard<std::mutex> g(g_tile_mu);
+    for (auto &e : g_rowbase_cache) if (e.device == dev && e.W == W && e.H == H && e.world == world) d_base = e.d_base;
+    if (!d_base) {
+      if (hipMalloc((void **)&d_base, (size_t)world * ty * sizeof(int32_t)) != hipSuccess) return fail(RT_ERR_OOM, "row-base table of %d entries", world * ty);
+      hipLaunchKernelGGL(k_make_row_base, dim3((unsigned)((world * ty + 255) / 256)), dim3(256), 0, stream, tx, ty, world, tile_skew(), d_base);
+      HIP_TRY(hipGetLastError());
+      if (stream != nullptr) HIP_TRY(hipStreamSynchronize(stream));   // later callers may use another stream
+      else HIP_TRY(hipDeviceSynchronize());
+      g_rowbase_cache.push_back({dev, W, H, world, d_base});
+    }
+  }
+  const size_t npx = (size_t)W * H;
+  hipLaunchKernelGGL(k_untile_all, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, d_base, tx, ty, world, tile_skew(), W, H, n_bytes,
+                     rank_stride_bytes, (const uint8_t *)d_packed_all, (uint8_t *)d_image);
+  HIP_TRY(hipGetLastError());
+  return RT_OK;
+}
+
 static int ensure_frame_buffers(Replica *s, size_t npx) {
   if (npx <= s->cap_px) return RT_OK;
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
@@ -1053,15 +1083,11 @@ static int render_single(Replica *s, const rt_camera *cam, const rt_params *p, r
   if ((rc = ensure_frame_buffers(s, npx))) return rc;
   hipStream_t stream = nullptr;
   HIP_TRY(hipEventRecord(s->ev0, stream));
-  rc = launch_render(s, s->ws, cam, p, 0, 1, false, s->d_color, out->radiance ? s->d_radiance : nullptr,
-                     out->prim_id ? s->d_primid : nullptr, stream);
+  // (k_resolve writes every requested form of the frame in its one pass, the 8-bit one included)
+  rc = launch_render(s, s->ws, cam, p, 0, 1, false, out->color ? s->d_color : nullptr, out->radiance ? s->d_radiance : nullptr,
+                     out->prim_id ? s->d_primid : nullptr, out->rgb8 ? s->d_rgb8 : nullptr, stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(s->ev1, stream));
-  if (out->rgb8) {
-    const long long n = (long long)npx * 3;
-    hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s->d_color, s->d_rgb8, n);
-    HIP_TRY(hipGetLastError());
-  }
   HIP_TRY(hipStreamSynchronize(stream));
   if (out->color) HIP_TRY(hipMemcpy(out->color, s->d_color, npx * 24, hipMemcpyDeviceToHost));
   if (out->radiance) HIP_TRY(hipMemcpy(out->radiance, s->d_radiance, npx * 24, hipMemcpyDeviceToHost));
@@ -1087,34 +1113,43 @@ static int render_group(rt_scene *sc, const rt_camera *cam, const rt_params *p, 
   const size_t npx = (size_t)W * H;
   Replica *r0 = sc->rep[0];
   const bool want_color = out->color != nullptr, want_rad = out->radiance != nullptr, want_id = out->prim_id != nullptr;
-  const bool bytes_only = out->rgb8 && !want_color;          // the 8-bit frame is all of the colour that is wanted
   int rc;
-  // ---- buffers: packed tiles on each replica's device, their landing place on device 0, the frame on device 0
+  // ---- buffers: packed tiles on each replica's device, their landing place on device 0 (slice i of replica 0's contiguous
+  //      gather areas), the frame on device 0
   size_t max_slots = 0;
   std::vector<int> n_tiles(N);
   for (int i = 0; i < N; ++i) { n_tiles[i] = rt_tile_count(W, H, i, N); max_slots = std::max(max_slots, (size_t)n_tiles[i] * 64); }
   HIP_TRY(hipSetDevice(r0->device));
   if ((rc = ensure_frame_buffers(r0, npx))) return rc;
-  for (int i = 0; i < N; ++i) {
-    Replica *r = sc->rep[i];
-    if (max_slots > r->cap_slots) {
+  if (max_slots > r0->cap_slots || r0->G_n != N) {
+    const size_t m = std::max<size_t>(max_slots, 64);
+    for (int i = 1; i < N; ++i) {                            // the other replicas' own packed buffers
+      Replica *r = sc->rep[i];
       HIP_TRY(hipSetDevice(r->device));
       (void)hipFree(r->p_color); (void)hipFree(r->p_radiance); (void)hipFree(r->p_primid); (void)hipFree(r->p_rgb8);
-      if (i > 0) { HIP_TRY(hipSetDevice(r0->device)); (void)hipFree(r->g_color); (void)hipFree(r->g_radiance); (void)hipFree(r->g_primid); (void)hipFree(r->g_rgb8); HIP_TRY(hipSetDevice(r->device)); }
-      r->p_color = r->p_radiance = r->g_color = r->g_radiance = nullptr; r->p_primid = r->g_primid = nullptr; r->p_rgb8 = r->g_rgb8 = nullptr; r->cap_slots = 0;
-      const size_t m = std::max<size_t>(max_slots, 64);
+      r->p_color = r->p_radiance = nullptr; r->p_primid = nullptr; r->p_rgb8 = nullptr; r->cap_slots = 0;
       if (hipMalloc((void **)&r->p_color, m * 24) != hipSuccess || hipMalloc((void **)&r->p_radiance, m * 24) != hipSuccess ||
           hipMalloc((void **)&r->p_primid, m * 4) != hipSuccess || hipMalloc((void **)&r->p_rgb8, m * 3) != hipSuccess)
         return fail(RT_ERR_OOM, "packed tile buffers for %zu slots on device %d", m, r->device);
-      if (i == 0) { r->g_color = r->p_color; r->g_radiance = r->p_radiance; r->g_primid = r->p_primid; r->g_rgb8 = r->p_rgb8; }
-      else {
-        HIP_TRY(hipSetDevice(r0->device));
-        if (hipMalloc((void **)&r->g_color, m * 24) != hipSuccess || hipMalloc((void **)&r->g_radiance, m * 24) != hipSuccess ||
-            hipMalloc((void **)&r->g_primid, m * 4) != hipSuccess || hipMalloc((void **)&r->g_rgb8, m * 3) != hipSuccess)
-          return fail(RT_ERR_OOM, "gather buffers for %zu slots on device %d", m, r0->device);
-      }
       r->cap_slots = m;
     }
+    HIP_TRY(hipSetDevice(r0->device));
+    (void)hipFree(r0->G_color); (void)hipFree(r0->G_radiance); (void)hipFree(r0->G_primid); (void)hipFree(r0->G_rgb8);
+    r0->G_color = r0->G_radiance = nullptr; r0->G_primid = nullptr; r0->G_rgb8 = nullptr; r0->cap_slots = 0; r0->G_n = 0;
+    if (hipMalloc((void **)&r0->G_color, (size_t)N * m * 24) != hipSuccess || hipMalloc((void **)&r0->G_radiance, (size_t)N * m * 24) != hipSuccess ||
+        hipMalloc((void **)&r0->G_primid, (size_t)N * m * 4) != hipSuccess || hipMalloc((void **)&r0->G_rgb8, (size_t)N * m * 3) != hipSuccess)
+      return fail(RT_ERR_OOM, "gather areas for %d x %zu slots on device %d", N, m, r0->device);
+    r0->cap_slots = m; r0->G_n = N;
+    for (int i = 0; i < N; ++i) {
+      Replica *r = sc->rep[i];
+      r->g_color = r0->G_color + (size_t)i * m * 3; r->g_radiance = r0->G_radiance + (size_t)i * m * 3;
+      r->g_primid = r0->G_primid + (size_t)i * m; r->g_rgb8 = r0->G_rgb8 + (size_t)i * m * 3;
+    }
+    r0->p_color = r0->g_color; r0->p_radiance = r0->g_radiance; r0->p_primid = r0->g_primid; r0->p_rgb8 = r0->g_rgb8;
+  }
+  const size_t m_slots = r0->cap_slots;
+  for (int i = 0; i < N; ++i) {
+    Replica *r = sc->rep[i];
     if (!r->stream) { HIP_TRY(hipSetDevice(r->device)); HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking)); }
   }
   // ---- fan out: one host thread per device (replaces the 24 green threads + TQueue of ImageGenerator.hs:37,64-94)
@@ -1127,17 +1162,14 @@ static int render_group(rt_scene *sc, const rt_camera *cam, const rt_params *p, 
       if (n_tiles[i] == 0) return RT_OK;
       const size_t slots = (size_t)n_tiles[i] * 64;
       HIP_TRY(hipEventRecord(r->ev0, r->stream));
-      int rc2 = launch_render(r, r->ws, cam, p, i, N, true, r->p_color, want_rad ? r->p_radiance : nullptr, want_id ? r->p_primid : nullptr, r->stream);
+      // k_resolve writes every requested form of the packed tiles in its one pass; the 8-bit frame crosses xGMI as 3 bytes per pixel
+      int rc2 = launch_render(r, r->ws, cam, p, i, N, true, want_color ? r->p_color : nullptr, want_rad ? r->p_radiance : nullptr,
+                              want_id ? r->p_primid : nullptr, out->rgb8 ? r->p_rgb8 : nullptr, r->stream);
       if (rc2) return rc2;
       HIP_TRY(hipEventRecord(r->ev1, r->stream));
-      if (bytes_only) {
-        const long long n = (long long)slots * 3;
-        hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r->stream, r->p_color, r->p_rgb8, n);
-        HIP_TRY(hipGetLastError());
-      }
       if (i > 0) {                                           // the exchange step: packed tiles to device 0
-        if (bytes_only) HIP_TRY(hipMemcpyPeerAsync(r->g_rgb8, r0->device, r->p_rgb8, r->device, slots * 3, r->stream));
-        else if (want_color || out->rgb8) HIP_TRY(hipMemcpyPeerAsync(r->g_color, r0->device, r->p_color, r->device, slots * 24, r->stream));
+        if (out->rgb8) HIP_TRY(hipMemcpyPeerAsync(r->g_rgb8, r0->device, r->p_rgb8, r->device, slots * 3, r->stream));
+        if (want_color) HIP_TRY(hipMemcpyPeerAsync(r->g_color, r0->device, r->p_color, r->device, slots * 24, r->stream));
         if (want_rad) HIP_TRY(hipMemcpyPeerAsync(r->g_radiance, r0->device, r->p_radiance, r->device, slots * 24, r->stream));
         if (want_id) HIP_TRY(hipMemcpyPeerAsync(r->g_primid, r0->device, r->p_primid, r->device, slots * 4, r->stream));
       }
@@ -1154,25 +1186,13 @@ static int render_group(rt_scene *sc, const rt_camera *cam, const rt_params *p, 
     for (auto &t : th) t.join();
   }
   for (int i = 0; i < N; ++i) if (rcs[i]) { g_err = errs[i]; return rcs[i]; }
-  // ---- assemble on device 0
+  // ---- assemble on device 0: one launch per requested output scatters the tiles of all replicas
   HIP_TRY(hipSetDevice(r0->device));
   hipStream_t st0 = r0->stream;
-  for (int i = 0; i < N; ++i) {
-    Replica *r = sc->rep[i];
-    if (n_tiles[i] == 0) continue;
-    if (bytes_only) { if ((rc = untile_launch(W, H, i, N, r->g_rgb8, r0->d_rgb8, 3, true, st0))) return rc; }
-    else if (want_color || out->rgb8) { if ((rc = untile_launch(W, H, i, N, r->g_color, r0->d_color, 3, false, st0))) return rc; }
-    if (want_rad && (rc = untile_launch(W, H, i, N, r->g_radiance, r0->d_radiance, 3, false, st0))) return rc;
-    if (want_id) {
-      static_assert(sizeof(int32_t) == 4, "prim ids travel as 4-byte slots");
-      if ((rc = untile_launch(W, H, i, N, r->g_primid, r0->d_primid, 4, true, st0))) return rc;
-    }
-  }
-  if (out->rgb8 && !bytes_only) {
-    const long long n = (long long)npx * 3;
-    hipLaunchKernelGGL(k_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st0, r0->d_color, r0->d_rgb8, n);
-    HIP_TRY(hipGetLastError());
-  }
+  if (out->rgb8 && (rc = untile_all_launch(W, H, N, r0->G_rgb8, m_slots * 3, r0->d_rgb8, 3, st0))) return rc;
+  if (want_color && (rc = untile_all_launch(W, H, N, r0->G_color, m_slots * 24, r0->d_color, 24, st0))) return rc;
+  if (want_rad && (rc = untile_all_launch(W, H, N, r0->G_radiance, m_slots * 24, r0->d_radiance, 24, st0))) return rc;
+  if (want_id && (rc = untile_all_launch(W, H, N, r0->G_primid, m_slots * 4, r0->d_primid, 4, st0))) return rc;
   HIP_TRY(hipStreamSynchronize(st0));
   if (out->color) HIP_TRY(hipMemcpy(out->color, r0->d_color, npx * 24, hipMemcpyDeviceToHost));
   if (out->radiance) HIP_TRY(hipMemcpy(out->radiance, r0->d_radiance, npx * 24, hipMemcpyDeviceToHost));
@@ -1208,9 +1228,9 @@ int rt_render(rt_scene *s, const rt_camera *cam, const rt_params *p, rt_output *
 }
 
 static int render_tiles_common(rt_scene *sc, Workspace &ws, const rt_camera *cam, const rt_params *p, int32_t rank, int32_t world,
-                               void *d_color, void *d_radiance, void *d_prim_id, void *stream, rt_stats *stats) {
+                               void *d_color, void *d_radiance, void *d_prim_id, void *d_rgb8, void *stream, rt_stats *stats) {
   Replica *s = sc->rep[0];
-  int rc = launch_render(s, ws, cam, p, rank, world, true, (double *)d_color, (double *)d_radiance, (int32_t *)d_prim_id, (hipStream_t)stream);
+  int rc = launch_render(s, ws, cam, p, rank, world, true, (double *)d_color, (double *)d_radiance, (int32_t *)d_prim_id, (uint8_t *)d_rgb8, (hipStream_t)stream);
   if (rc) return rc;
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
@@ -1230,7 +1250,17 @@ int rt_render_tiles_device(rt_scene *s, const rt_camera *cam, const rt_params *p
   if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad rank/world");
   if (!d_color && !d_radiance && !d_prim_id) return fail(RT_ERR_INVALID, "no output buffer");
   HIP_TRY(hipSetDevice(s->rep[0]->device));
-  return render_tiles_common(s, s->rep[0]->ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, stream, stats);
+  return render_tiles_common(s, s->rep[0]->ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, nullptr, stream, stats);
+}
+
+int rt_render_tiles_rgb8_device(rt_scene *s, const rt_camera *cam, const rt_params *p, int32_t rank, int32_t world,
+                                void *d_rgb8, void *stream, rt_stats *stats) {
+  int rc = check_frame(s, cam, p);
+  if (rc) return rc;
+  if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "bad rank/world");
+  if (!d_rgb8) return fail(RT_ERR_INVALID, "no output buffer");
+  HIP_TRY(hipSetDevice(s->rep[0]->device));
+  return render_tiles_common(s, s->rep[0]->ws, cam, p, rank, world, nullptr, nullptr, nullptr, d_rgb8, stream, stats);
 }
 
 // The same frame share with NO allocation anywhere on the way: the launch workspace is the static device array
@@ -1258,7 +1288,7 @@ int rt_render_tiles_device_noalloc(rt_scene *s, const rt_camera *cam, const rt_p
   // every call shares this GPU's array and finds the previous call's contents in it: the counter is cleared per launch
   // (launch_kernel), the statistics when they are collected, the tile list is rewritten, records and samples are
   // written before they are read
-  return render_tiles_common(s, ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, stream, stats);
+  return render_tiles_common(s, ws, cam, p, rank, world, d_color, d_radiance, d_prim_id, nullptr, stream, stats);
 }
 
 int rt_kernel_name(rt_scene *sc, const rt_params *p, char *buf, int32_t cap) {
@@ -1306,6 +1336,17 @@ int rt_untile_bytes_device(int32_t W, int32_t H, int32_t rank, int32_t world, co
   if (rc) return rc;
   if (!d_packed || !d_image || n_bytes <= 0) return fail(RT_ERR_INVALID, "bad untile arguments");
   return untile_launch(W, H, rank, world, d_packed, d_image, n_bytes, true, (hipStream_t)stream);
+}
+
+int rt_untile_all_bytes_device(int32_t W, int32_t H, int32_t world, const void *d_packed_all, int64_t rank_stride_bytes,
+                               void *d_image, int32_t n_bytes, void *stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!d_packed_all || !d_image || n_bytes <= 0 || rank_stride_bytes < 0) return fail(RT_ERR_INVALID, "bad untile arguments");
+  for (int r = 0; r < world; ++r)
+    if ((int64_t)rt_tile_count(W, H, r, world) * 64 * n_bytes > rank_stride_bytes)
+      return fail(RT_ERR_INVALID, "rank %d's %d tiles do not fit a stride of %lld bytes", r, rt_tile_count(W, H, r, world), (long long)rank_stride_bytes);
+  return untile_all_launch(W, H, world, d_packed_all, (size_t)rank_stride_bytes, d_image, n_bytes, (hipStream_t)stream);
 }
 
 int rt_quantize_device(const void *d_color, void *d_rgb8, int64_t n_values, void *stream) {

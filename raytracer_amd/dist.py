@@ -75,6 +75,22 @@ def untile_into(image: torch.Tensor, packed: torch.Tensor, width, height, rank, 
     return image
 
 
+def make_gather_buffers(packed: torch.Tensor, world) -> list:
+    """Rank 0's landing buffers of the gather as views of ONE contiguous (world, slots, C) tensor, so that the un-tiling of all
+    ranks is a single launch (rt_untile_all_bytes_device)."""
+    big = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    bufs = [big[r] for r in range(world)]
+    bufs[0]._rt_big = big                                # keeps the parent reachable from the list
+    return bufs
+
+
+def _contiguous_parent(bufs, packed):
+    big = getattr(bufs[0], "_rt_big", None)
+    if big is None or not big.is_cuda or big.shape[1:] != packed.shape or big.dtype != packed.dtype:
+        return None
+    return big
+
+
 def gather_frame(packed: torch.Tensor, width, height, rank, world, image: torch.Tensor | None = None,
                  gather_buffers: list | None = None, force_collective: bool = False):
     """The exchange step.  packed: (max_tiles*64, C) on every rank (padded to the largest tile count so
@@ -89,6 +105,13 @@ def gather_frame(packed: torch.Tensor, width, height, rank, world, image: torch.
         dist.gather(packed, gather_list=bufs, dst=0)
         if image is None:
             image = torch.empty((height, width, n_comp), dtype=packed.dtype, device=packed.device)
+        big = _contiguous_parent(bufs, packed)
+        if big is not None:                      # device buffers from make_gather_buffers: all ranks in one launch
+            stream = torch.cuda.current_stream().cuda_stream
+            slot_bytes = n_comp * packed.element_size()
+            F.check(F.core().rt_untile_all_bytes_device(width, height, world, C.c_void_p(big.data_ptr()), packed.shape[0] * slot_bytes,
+                                                        C.c_void_p(image.data_ptr()), slot_bytes, C.c_void_p(stream)))
+            return image
         for r in range(world):
             untile_into(image, bufs[r], width, height, r, world)
         return image

@@ -66,9 +66,11 @@ def test_bench_rccl_code_path_with_one_rank(need_gpu):
     env = dict(os.environ, RT_BENCH_FORCE_DIST="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--width", "320", "--height", "180", "--spp", "4", "--no-cpu-baseline"]
+           "--width", "320", "--height", "180", "--spp", "4", "--no-cpu-baseline", "--others", ""]
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["kernel_ms"] > 0
+    assert j["rr"]["rr_start_bounce"] == 2 and j["rr"]["rays_per_frame"] < j["config"]["rays_per_frame"]
+    assert j["roofline"]["kernel"].startswith("k_render_tiles<float, false, true, false>") and len(j["roofline"]["build_id"]) == 16

@@ -50,3 +50,54 @@ def test_init_devices_rejects_bad_ids(need_gpu):
     bad = np.array([0, 99], np.int32)
     assert F.core().rt_init_devices(2, bad.ctypes.data_as(F.c_int32_p)) == F.RT_ERR_INVALID
     F.check(F.core().rt_init(-1))
+
+
+def test_group_is_not_replaced_by_a_call_from_another_thread(need_gpu):
+    """an entry point reached from a fresh OS thread (a GHC `safe` ccall on another capability) must not
+    re-initialise the library and turn the group into [current device]."""
+    import threading
+    lib = F.core()
+    ids = np.array([0, 0, 0], np.int32)
+    F.check(lib.rt_init_devices(3, ids.ctypes.data_as(F.c_int32_p)))
+    rcs = []
+
+    def other():
+        rcs.append(lib.rt_quantize_device(None, None, 0, None))       # runs ensure_init, then rejects the null buffers
+        spec = scenes.c2_spheres(width=32, height=16, spp=1)
+        g = api.GpuScene.__new__(api.GpuScene)                        # rt_scene_create without a preceding rt_init
+        g.spec = spec
+        import ctypes as C
+        desc = F.rt_scene_desc()
+        keep = []
+        k, d, m = spec.all_objects()
+        g.bvh = api.HostBvh(k, d, m, spec.leaf_threshold, spec.bvh_max_depth)
+        g.bvh.fill(desc)
+        api.fill_desc_common(desc, spec, keep)
+        g._h = C.c_void_p()
+        rcs.append(lib.rt_scene_create(C.byref(desc), C.byref(g._h)))
+        rcs.append(lib.rt_device_count())
+        g.close()
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert rcs == [F.RT_ERR_INVALID, F.RT_OK, 3], rcs
+    assert lib.rt_device_count() == 3
+    F.check(lib.rt_init(-1))
+
+
+@pytest.mark.timeout(300)
+def test_bench_single_process_group_line(need_gpu):
+    """bench.py --single-process: the metric through rt_init_devices + ONE rt_render per frame (the path the Haskell host
+    binds), here on two virtual devices of the one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--devices", "0,0",
+                          "--workload", "c3", "--width", "320", "--height", "180", "--spp", "4", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=280, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"].startswith("group2") and line["value"] > 0

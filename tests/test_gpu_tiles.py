@@ -59,6 +59,40 @@ def test_eight_bit_frame_gathered_as_bytes(need_gpu, world):
     assert np.array_equal(rgb8.cpu().numpy(), full["rgb8"])
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_fused_eight_bit_tiles_and_one_launch_untile(need_gpu, world):
+    """bench.py's step: rt_render_tiles_rgb8_device writes the rank's packed 8-bit tiles in the resolve pass (no colour buffer,
+    no quantise launch); the ranks' buffers, laid side by side as the gather leaves them (dist.make_gather_buffers), are
+    un-tiled by ONE rt_untile_all_bytes_device launch.  The frame must equal rt_render's rgb8, and the same launch must
+    reproduce the colour frame from packed doubles (24-byte slots)."""
+    import torch
+    spec = scenes.c3_blob988(width=203, height=117, spp=2)
+    g = api.GpuScene(spec)
+    full, _ = g.render(want=("rgb8", "color"))
+    W, H = spec.width, spec.height
+    n_max = rdist.max_tiles(W, H, world)
+    stream = torch.cuda.current_stream().cuda_stream
+    packed8 = torch.zeros((n_max * 64, 3), dtype=torch.uint8, device="cuda")
+    bufs8 = rdist.make_gather_buffers(packed8, world)
+    packed = torch.zeros((n_max * 64, 3), dtype=torch.float64, device="cuda")
+    bufs = rdist.make_gather_buffers(packed, world)
+    for rank in range(world):
+        g.render_tiles_device(rank, world, d_rgb8=bufs8[rank].data_ptr(), stream=stream)
+        g.render_tiles_device(rank, world, d_color=bufs[rank].data_ptr(), stream=stream)
+    rgb8 = torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda")
+    col = torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda")
+    F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs8[0]._rt_big.data_ptr()), n_max * 64 * 3,
+                                                C.c_void_p(rgb8.data_ptr()), 3, C.c_void_p(stream)))
+    F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs[0]._rt_big.data_ptr()), n_max * 64 * 24,
+                                                C.c_void_p(col.data_ptr()), 24, C.c_void_p(stream)))
+    torch.cuda.synchronize()
+    g.close()
+    assert np.array_equal(rgb8.cpu().numpy(), full["rgb8"])
+    assert np.array_equal(col.cpu().numpy(), full["color"])
+    with pytest.raises(F.RtError):                           # a stride that cannot hold a rank's tiles is refused on the host
+        F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs8[0]._rt_big.data_ptr()), 64, C.c_void_p(rgb8.data_ptr()), 3, None))
+
+
 def test_quantize_device_matches_host_rule(need_gpu):
     import torch
     c = torch.tensor([0.0, 0.5, 0.999999, 1.0, 0.0039, 1.7, -0.2, float("nan")], dtype=torch.float64, device="cuda")

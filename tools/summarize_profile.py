@@ -75,7 +75,18 @@ def main():
         out[k] = {"launch": meta.get(k, {}), "counters_per_launch": per, "derived": der}
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 
-    main_k = [k for k in out if "<float, false" in k]     # the timed variant: FP32 boxes, no STATS counters
+    # the kernel the bench line of the SAME run names (roofline.kernel = rt_kernel_name) and the digest of the sources it was
+    # built from (roofline.build_id = rt_build_id): the counter record is tied to both, bench.py calls it stale otherwise
+    bench_line = {}
+    for ln in open(os.path.join(src, "kt.log"), errors="replace"):
+        if ln.startswith("{") and '"roofline"' in ln:
+            bench_line = json.loads(ln)
+    timed_name = bench_line.get("roofline", {}).get("kernel")
+    build_id = bench_line.get("roofline", {}).get("build_id")
+    if timed_name:
+        main_k = [k for k in out if timed_name + "(" in k or k.endswith(timed_name) or (timed_name in k)]
+    else:
+        main_k = [k for k in out if "<float, false" in k]     # (older logs) the timed variant: FP32 boxes, no STATS counters
     lines = [f"# rocprofv3 summary {tag} — `bench.py` ({workload_key})", "",
              "Source: `tools/profile.sh` on one MI355X; one rocprofv3 run per pass (kernel trace, then PMC passes).", "",
              "## kernel-trace --stats", "", "| kernel | calls | avg ms | % |", "|---|---|---|---|"]
@@ -96,7 +107,8 @@ def main():
         d = out[k]["derived"]
         if "hbm_read_bytes_x2_gfx950" in d:
             traffic[workload_key] = {"hbm_bytes_per_launch": int(d["hbm_read_bytes_x2_gfx950"] + d.get("hbm_write_bytes", 0)),
-                                     "source": f"profiles/{tag}_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"}
+                                     "source": f"profiles/{tag}_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                                     "build_id": build_id, "kernel": timed_name}
             # the limiter that matters for this kernel: VALU issue.  SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of a
             # wave's life spent issuing VALU work; times the resident waves per SIMD = how busy each SIMD's VALU is.
             if "frac_wave_cycles_valu(SQ_ACTIVE_INST_VALU)" in d and "resident_waves_per_simd" in d:
