@@ -28,6 +28,8 @@ CASES=(
   "c3_mean|c3_blob988(width=320, height=180, spp=256)|mean"
   "c4_mean|c4_blob63k(width=320, height=180, spp=256)|mean"
 )
+# RT_REF_CASES="name|ctor|kind;name|ctor|kind": another case list (tests/test_reference_hook.py feeds the script a fake `cabal`)
+if [ -n "${RT_REF_CASES:-}" ]; then IFS=';' read -r -a CASES <<< "$RT_REF_CASES"; fi
 status=0
 for c in "${CASES[@]}"; do
   IFS='|' read -r name ctor kind <<< "$c"

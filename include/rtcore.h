@@ -258,7 +258,10 @@ int  rt_render_tiles_rgb8_device(rt_scene *scene, const rt_camera *cam, const rt
  * correctness; one workgroup's path records must fit 62 MiB (always true for BVH depth <= 60).  Beyond them:
  * RT_ERR_UNSUPPORTED.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU race (the same holds
  * for two rt_render_tiles_device calls in flight on ONE rt_scene - at most one render in flight per scene, and successive
- * calls on a scene must be stream-ordered).  rt_kernel_times does not see these launches (creating an event allocates). */
+ * calls on a scene must be stream-ordered).  rt_kernel_times does not see these launches (creating an event allocates).
+ * Under stream capture pass stats = NULL or params->collect_stats = 0: collecting the counters synchronises the stream and
+ * copies them to the host (a blocking hipMemcpy), which is illegal while capturing; with collect_stats = 0 the call only
+ * enqueues memsets and kernels on `stream` (tests/test_zz_no_alloc.py captures it into a graph and replays it). */
 int  rt_render_tiles_device_noalloc(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                                     int32_t rank, int32_t world,
                                     void *d_color, void *d_radiance, void *d_prim_id,

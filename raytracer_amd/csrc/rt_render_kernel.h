@@ -286,8 +286,14 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         camera_ray(fr, (int)(pixel % (uint32_t)fr.W), (int)(pixel / (uint32_t)fr.W), pixel, (uint32_t)sb.x, o_, bgdir);
       }
       const d3 att = rec_ld(lrec, LR_ATT), fa = rec_ld(lrec, LR_FA), fl = rec_ld(lrec, LR_FL), fh = rec_ld(lrec, LR_FH);
-      d3 T = att * background(sc, bgdir);
-      if (RR) T = rec[PR_S * 64] * T;       // (extension) the roulette weight of this depth
+      d3 T = mk3(0, 0, 0);
+      // (extension) a path the roulette terminated (bounce counter -1) adds NOTHING deeper: no background lookup - 0 x an
+      // infinite sky texel would be NaN where the definition (oracle.cpp traceLoop) returns emitted + lit
+      const bool dead = RR && rec_ldi(lrec, LR_SB).y < 0;
+      if (!dead) {
+        T = att * background(sc, bgdir);
+        if (RR) T = rec[PR_S * 64] * T;     // (extension) the roulette weight of this depth
+      }
       const d3 R = clamp3(T + fa, fl, fh);
       double *o_ = fr.samples + 3 * (size_t)item;
       // written once, read once by k_resolve after the launch: non-temporal, so that the stream (5 GB on C4, 51 GB on C5) does not
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           rec_sti(lrec, LR_SB, sb.x, sb.y);
           li = -1;
           if (sb.y >= fr.maxb) { need_ray0 = true; need_finish = true; }         // depth 0: background along ray0, :22
-          if (rr_dead) need_finish = true;                                       // (extension) att = 0: the sample is clamp(a, L, H)
+          if (rr_dead) { need_finish = true; rec_sti(lrec, LR_SB, sb.x, -1); }   // (extension) the sample is clamp(a, L, H): finish_paths adds no background
         }
         RT_MARK("SH_SCATTER_END");
         RT_TICK_SH(9);

@@ -38,3 +38,24 @@ def test_rr_is_unbiased_where_no_clamp_is_active(need_gpu):
     rms = np.sqrt(np.mean(d ** 2))
     assert rms <= 3.0 * noise
     assert abs(d.mean()) <= 4.0 * rms / np.sqrt(d.shape[0] * d.shape[1])
+
+
+def test_terminated_paths_do_not_sample_the_sky(need_gpu):
+    """a path the roulette terminates adds nothing deeper - in particular not 0 x background.  With an infinite
+    texel in an RGBF sky that product would be NaN; the definition (the oracle) returns emitted + lit."""
+    spec = scenes.c3_blob988(width=96, height=54, spp=8)
+    sky = scenes.sky_gradient_texture(fmt="rgbf")
+    img = sky[1].copy()
+    img[: img.shape[0] // 2] = np.inf                       # the whole upper half of the sky
+    spec.sky = ("rgbf", img)
+    o = O.OracleScene(spec)
+    ref = o.render(rr_start_bounce=1)
+    o.close()
+    g = api.GpuScene(spec)
+    res, _ = g.render(rr_start_bounce=1)
+    g.close()
+    assert np.isfinite(ref["radiance"]).sum() > 0 and not np.isnan(ref["radiance"]).all()
+    assert np.array_equal(np.isnan(res["radiance"]), np.isnan(ref["radiance"]))
+    assert np.array_equal(np.isinf(res["radiance"]), np.isinf(ref["radiance"]))
+    ok = np.isfinite(ref["radiance"])
+    assert np.abs(res["radiance"][ok] - ref["radiance"][ok]).max() <= 1e-12 * max(1.0, np.abs(ref["radiance"][ok]).max())

@@ -41,3 +41,50 @@ def test_differ_verdicts(tmp_path):
 def test_script_names_the_documented_invocation():
     s = open(os.path.join(ROOT, "bench", "run_reference.sh")).read()
     assert "cabal run -v0 raytracer" in s and "+RTS -N -qg -A32M" in s and "Time taken" in s
+
+
+FAKE_CABAL = r"""#!/bin/bash
+# stands in for `cabal run -v0 raytracer <config.json> +RTS ...` (the real one needs GHC): renders the config with the
+# repository's oracle into out/<timestamp>.ppm like Main.hs:48-58 and prints the line the script greps for
+cfg=""
+for a in "$@"; do case "$a" in *.json) cfg="$a";; esac; done
+mkdir -p out
+python3 "$RT_REPO/tools/oracle_ppm.py" "$cfg" out/20250101-000000.ppm > /dev/null
+if [ "${FAKE_PERTURB:-0}" != "0" ]; then
+python3 - out/20250101-000000.ppm "$FAKE_PERTURB" <<'PY'
+import sys
+tok = open(sys.argv[1]).read().split()
+d = int(sys.argv[2])
+vals = [str(min(255, max(0, int(v) + (d if i % 2 else -d)))) for i, v in enumerate(tok[4:])]
+open(sys.argv[1], "w").write("P3\n%s %s\n%s\n" % (tok[1], tok[2], tok[3]) + "\n".join(vals) + "\n")
+PY
+fi
+echo "Time taken to create and write file: 1.23s"
+"""
+
+
+def run_hook(tmp_path, perturb):
+    ref = tmp_path / "checkout"; ref.mkdir(exist_ok=True)
+    bindir = tmp_path / "bin"; bindir.mkdir(exist_ok=True)
+    cabal = bindir / "cabal"
+    cabal.write_text(FAKE_CABAL)
+    cabal.chmod(0o755)
+    env = dict(os.environ, PATH=f"{bindir}:{os.environ['PATH']}", RT_REPO=ROOT, FAKE_PERTURB=str(perturb),
+               RT_REF_CASES="t_det|c1_testing(width=64, height=36, spp=1)|det;t_mean|c2_spheres(width=32, height=18, spp=8)|mean")
+    return subprocess.run(["bash", os.path.join(ROOT, "bench", "run_reference.sh"), str(ref), str(tmp_path / "work")],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_hook_passes_on_equal_frames_and_fails_on_a_two_level_shift(tmp_path):
+    """the script has never met a real `cabal`; a fake one that produces the oracle's own frame must make
+    it pass (exit 0, the reference's time line reported), and the same frame shifted by +-2 levels must fail the deterministic
+    case (<= 1 level on >= 99.99 % of the values) while the mean-image case (PSNR >= 30 dB) still passes; +-40 levels fails both."""
+    ok = run_hook(tmp_path, 0)
+    assert ok.returncode == 0, ok.stdout[-1500:] + ok.stderr[-1500:]
+    assert ok.stdout.count("PASS") == 2 and "Time taken to create and write file" in ok.stdout
+    two = run_hook(tmp_path, 2)
+    assert two.returncode == 1, two.stdout[-1500:]
+    lines = [l for l in two.stdout.splitlines() if l in ("PASS", "FAIL")]
+    assert lines == ["FAIL", "PASS"], two.stdout[-1500:]
+    forty = run_hook(tmp_path, 40)
+    assert forty.returncode == 1 and [l for l in forty.stdout.splitlines() if l in ("PASS", "FAIL")] == ["FAIL", "FAIL"]

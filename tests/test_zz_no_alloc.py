@@ -60,3 +60,38 @@ def test_noalloc_rejects_what_does_not_fit(need_gpu):
         render_packed(g, 0, 1, noalloc=True, samples_per_pixel=50000)          # one tile's samples: 76.8 MB > 64 MiB
     assert e.value.code == F.RT_ERR_UNSUPPORTED and "static scratch" in str(e.value)
     g.close()
+
+
+def test_noalloc_call_allocates_nothing(need_gpu):
+    """nothing asserted that the entry point allocates nothing.  Free device memory (hipMemGetInfo through
+    torch) must not move across noalloc calls - while the allocating twin, on a fresh scene, visibly grows its workspace -
+    and with collect_stats = 0 the call must be legal under HIP stream capture (no synchronisation, no blocking copy)."""
+    import torch
+    spec = scenes.c3_blob988(width=203, height=117, spp=24)
+    g = api.GpuScene(spec)
+    n = rdist.max_tiles(spec.width, spec.height, 1)
+    col = torch.zeros((n * 64, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(2):
+        g.render_tiles_device(0, 1, d_color=col.data_ptr(), stream=stream, noalloc=True)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    g.render_tiles_device(0, 1, d_color=col.data_ptr(), stream=stream, noalloc=False)      # grows the scene's own workspace
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free0
+    # under capture: a side stream, the call recorded into a graph, the graph replayed
+    ref = col.clone()
+    col.zero_()
+    s = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        gr.capture_begin()
+        g.render_tiles_device(0, 1, d_color=col.data_ptr(), stream=s.cuda_stream, noalloc=True)
+        gr.capture_end()
+    torch.cuda.synchronize()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(col, ref)
+    g.close()
