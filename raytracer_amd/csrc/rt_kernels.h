@@ -27,7 +27,10 @@ struct KScene {
   const DMaterial *mats;
   const DLight *lights;
   const double *plane_boxes;   // 6 doubles per plane: the FP64 box of the leaf holding it
-  const double *tri_normals;   // 6 doubles per primitive (triangles only): n = normalize(e1 x e2) (Triangle.hs:51) and normalize(n) (Light.hs:19)
+  // What shading reads of a hit, ONE 64-byte line per primitive (reference order): doubles 0-2 n = normalize(e1 x e2) (Triangle.hs:51),
+  // 3-5 normalize(n) (Light.hs:19) (triangles only), then the int pair (material index, kind) of DPrim; 8 bytes of padding.
+  // (The pair used to be read from the 80-byte primitive and the normals from a 48-byte table: three lines in two arrays per hit.)
+  const double *shade_recs;
   const void *sky;
   const double *sky_u_tab;     // (cos phi_k, sin phi_k), phi_k = 2 pi (k / w - 0.5), k = -2 .. w + 2: the texel columns' boundary directions
   const double *sky_v_tab;     // cos(pi k / h), k = -2 .. h + 2 (+inf below 0, -inf above h): the texel rows' thresholds on y

@@ -523,6 +523,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         }
         if (STATS && isl && kind == RT_PRIM_TRIANGLE) st[STAT_TRI]++;
         if (__ballot(isl && kind != RT_PRIM_TRIANGLE) != 0ull) {   // wave-uniform: leaves with spheres/planes are rare
+          RT_MARK("PRIM_NONTRI_BEGIN");
           // The ray enters this branch through an opaque copy: otherwise the compiler hoists what depends on the ray alone
           // (the plane's three FP64 reciprocals 1/d and its parallel-axis tests, the sphere's d.d: ~55 of ~190 VALU
           // instructions) in front of the branch and every triangle test pays for it.
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             }
           }
         }
+        RT_MARK("PRIM_NONTRI_END");
         h = h && isl;
         // FAST: this tree's order is not the reference's.  FP32 boxes on the reference's tree: two children's entry distances
         // can compare differently after rounding, so the visiting order is not always the reference's either.  Both settle
@@ -586,8 +588,10 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         if constexpr (FAST || sizeof(BT) == 4) {
           const bool tie = h && li < 0 && best >= 0 && t == best_t;
           if (__ballot(tie) != 0ull) {
+            RT_MARK("PRIM_TIE_BEGIN");
             if (tie) h = tie_candidate_wins(sc.leaf_anc, sc.ref_anc, sc.ref_depth, (const DNode<double> *)sc.ref_nodes64,
                                             ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, FAST ? (int)P.mat : pi, best);
+            RT_MARK("PRIM_TIE_END");
           }
         }
         best_t = h ? t : best_t;                             // t <= best_t: a later element wins ties
@@ -636,9 +640,10 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         {
           RT_COLD_ARGS();
           const size_t pidx = (size_t)(uint32_t)(is_h ? best : (anyhit ? (hitp & ~HITP_FRONT) : 0));   // primitive just hit / of the pending hit
-          pkm = *(const int2 *)((const char *)sc.prims + pidx * 80u + 72u);
-          tn = ld3(sc.tri_normals + 6 * pidx);
-          tn2 = ld3(sc.tri_normals + 6 * pidx + 3);
+          const double *sr_ = sc.shade_recs + 8 * pidx;       // one 64-byte line
+          pkm = *(const int2 *)(sr_ + 6);
+          tn = ld3(sr_);
+          tn2 = ld3(sr_ + 3);
           // Round 2: the material (a small, cache-resident table); the face-forwarded normal of a triangle hit is
           // not kept in the record, it is +-n of the remembered primitive.
           if (anyhit) {

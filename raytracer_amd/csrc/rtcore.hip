@@ -357,7 +357,7 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
   // re-normalisation computeLighting applies to it (Light.hs:19).  Same operations in the same order as the device
   // helpers cross3 / dot3 / normalize3 (rt_device.h), IEEE sqrt and division, no contraction: bit-identical values.
   std::vector<double> &tri_normals = hs.tri_normals;
-  tri_normals.assign((size_t)np * 6, 0.0);
+  tri_normals.assign((size_t)np * 8, 0.0);   // 64-byte shading records: n, normalize(n), (material, kind), pad
   auto normalize_like_device = [](const double v[3], double out[3]) {
     const double s = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     out[0] = s * v[0]; out[1] = s * v[1]; out[2] = s * v[2];
@@ -379,8 +379,8 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
         }
         const double *a = P.d + 3, *b = P.d + 6;
         const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-        normalize_like_device(c, &tri_normals[6 * i]);
-        normalize_like_device(&tri_normals[6 * i], &tri_normals[6 * i + 3]);
+        normalize_like_device(c, &tri_normals[8 * i]);
+        normalize_like_device(&tri_normals[8 * i], &tri_normals[8 * i + 3]);
       } else {
         for (int k = 0; k < 9; ++k) P.d[k] = src[k];
         if (kind == RT_PRIM_PLANE) P.d[6] = -1.0;
@@ -413,6 +413,10 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
   }
   for (int i = 0; i < np; ++i)
     if (!in_leaf[i]) { return fail(RT_ERR_INVALID, "primitive %d belongs to no leaf of the tree", i); }
+  for (int i = 0; i < np; ++i) {                              // the (material, kind) pair of the shading records
+    const int32_t pr[2] = {prims[i].mat, (int32_t)prims[i].kind};
+    std::memcpy(&tri_normals[8 * (size_t)i + 6], pr, sizeof pr);
+  }
   for (int q = 0; q < 6; ++q) maxabs = std::max(maxabs, std::fabs(d->node_bounds[q]));
 
   // ---- internal nodes: children's boxes, FP64 as given and FP32 rounded outward
@@ -626,7 +630,7 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
   k.nodes = s->d_nodes32; k.prims = s->d_prims; k.tprims = s->d_prims;
   k.ref_nodes64 = s->d_nodes64; k.ref_anc = s->d_ref_anc; k.ref_depth = s->d_ref_depth; k.leaf_anc = s->d_leaf_anc;
   k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
-  k.plane_boxes = s->d_plane_boxes; k.tri_normals = s->d_tri_normals; k.sky = s->d_sky; k.sky_u_tab = s->d_sky_u_tab; k.sky_v_tab = s->d_sky_v_tab;
+  k.plane_boxes = s->d_plane_boxes; k.shade_recs = s->d_tri_normals; k.sky = s->d_sky; k.sky_u_tab = s->d_sky_u_tab; k.sky_v_tab = s->d_sky_v_tab;
   *out = s;
   return RT_OK;
 }
