@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--others", default="c2,c3,c5", help="N = 1 only: further workloads measured with the same binary into `other_workloads` ('' = none)")
     ap.add_argument("--no-rr", action="store_true", help="skip the Russian-roulette block")
+    ap.add_argument("--no-reference-count", action="store_true", help="skip the untimed box_precision=1 counting pass (roofline.reference_algorithm): profiling runs")
     ap.add_argument("--single-process", action="store_true", help="rt_init_devices + ONE rt_render per frame on --gpus devices of this process")
     ap.add_argument("--devices", default=None, help="--single-process: comma-separated device ids (may repeat: virtual devices)")
     args = ap.parse_args()
@@ -266,7 +267,7 @@ def main():
     ctx = Ctx(args.gpus)
     rank, world = ctx.rank, ctx.world
     spec = make_spec(args.workload, args.width, args.height, args.spp)
-    m = measure(ctx, spec, args.steps, args.warmup)
+    m = measure(ctx, spec, args.steps, args.warmup, count_reference=not args.no_reference_count)
     W, H = spec.width, spec.height
     tot = m["tot"]
     rays_total = tot[0] + tot[1]

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for v in "$@"; do
   name=${v%%:*}; lib=${v#*:}
   for rep in 1 2; do
-    RTCORE_LIB=$lib timeout -k 10 300 python3 -u bench.py --no-cpu-baseline --no-rr --others= $ARGS 2> gpurun_out/ab_$name.err | python3 -c "
+    RTCORE_LIB=$lib timeout -k 10 300 python3 -u bench.py --no-cpu-baseline --no-rr --no-reference-count --others= $ARGS 2> gpurun_out/ab_$name.err | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -4,7 +4,7 @@ set -u
 ARGS=$1; shift
 mkdir -p gpurun_out
 for v in "$@"; do
-  env $v timeout -k 10 300 python3 -u bench.py --no-cpu-baseline --no-rr --others= $ARGS 2> gpurun_out/abenv.err | python3 -c "
+  env $v timeout -k 10 300 python3 -u bench.py --no-cpu-baseline --no-rr --no-reference-count --others= $ARGS 2> gpurun_out/abenv.err | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

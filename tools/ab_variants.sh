@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 out=gpurun_out/ab_variants.txt; : > $out
 for lib in raytracer_amd/lib/librtcore.so raytracer_amd/lib/variants/*.so; do
   [ -f "$lib" ] || continue
-  RTCORE_LIB=$lib timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rr --others= "$@" > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$lib FAILED" >> $out; exit 1; }
+  RTCORE_LIB=$lib timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-rr --no-reference-count --others= "$@" > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$lib FAILED" >> $out; exit 1; }
   echo "$lib $(grep -o '"kernel_ms": [0-9.]*' gpurun_out/ab_tmp.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ab_tmp.json)" >> $out
 done
 cat $out

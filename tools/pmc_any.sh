@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmca_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 [ "$LIB" != "-" ] && export RTCORE_LIB=$R/$LIB
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-rr --others= --steps 1 --warmup 0 $ARGS"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-rr --no-reference-count --others= --steps 1 --warmup 0 $ARGS"
 n=0
 for pass in "$@"; do
   n=$((n+1))

@@ -4,7 +4,7 @@ set -u
 TAG=$1; R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/pmcm_$TAG; mkdir -p "$OUT"
 [ $# -ge 2 ] && export RTCORE_LIB=$R/$2
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-rr --others= --steps 1 --warmup 0"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-rr --no-reference-count --others= --steps 1 --warmup 0"
 run() { n=$1; shift; timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$n" -o $n -- $BENCH > "$OUT/$n.log" 2>&1 || { echo "pass $n failed"; tail -5 "$OUT/$n.log"; exit 1; }; }
 run a TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE GRBM_COUNT
 run b TA_FLAT_READ_WAVEFRONTS_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmcq_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export RTCORE_LIB=$R/$LIB
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-rr --others= --steps 1 --warmup 0 $*"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-rr --no-reference-count --others= --steps 1 --warmup 0 $*"
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/a" -o a -- $BENCH > "$OUT/a.log" 2>&1 || { tail -5 "$OUT/a.log"; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 --output-format csv -d "$OUT/b" -o b -- $BENCH > "$OUT/b.log" 2>&1 || { tail -5 "$OUT/b.log"; exit 1; }
 python3 - "$OUT" <<'PY'
