@@ -483,8 +483,12 @@ inline double schlick(double cosine, double refIdx) {                        // 
   double r0sq = r0 * r0;
   return r0sq + (1 - r0sq) * std::pow(1 - cosine, 5);
 }
-inline V3 clampV(V3 c, double lo, double hi) {                               // :91-94
-  auto cl = [&](double v) { return std::max(lo, std::min(hi, v)); };
+// GHC's Ord Double defaults (GHC.Classes): max x y = if x <= y then y else x; min x y = if x <= y then x else y.  On a NaN they are
+// not std::max / std::min / fmax / fmin: min hi NaN = NaN, max lo NaN = lo - the reference's clamp turns a NaN bounce term into lo.
+inline double hsMin(double x, double y) { return x <= y ? x : y; }
+inline double hsMax(double x, double y) { return x <= y ? y : x; }
+inline V3 clampV(V3 c, double lo, double hi) {                               // :91-94  cl v = max lo (min hi v)
+  auto cl = [&](double v) { return hsMax(lo, hsMin(hi, v)); };
   return {cl(c.x), cl(c.y), cl(c.z)};
 }
 inline V3 toneMap(double e, V3 c) {                                          // :96-101
@@ -534,7 +538,7 @@ V3 traceLoop(const Scene &s, const Ray &ray0, const Ray &ray, int depth, V3 atte
   if (transIsOne && mat.hasIor) {                                            // :48-59
     double refIdx = mat.ior;
     double eta = tfrontFace ? 1.0 / refIdx : refIdx;                         // :50
-    double cosTheta = std::min(-dot(unitDir, outwardNormal), 1.0);           // :51
+    double cosTheta = hsMin(-dot(unitDir, outwardNormal), 1.0);              // :51 (GHC's min: 1.0 on a NaN)
     double sinTheta = std::sqrt(1.0 - cosTheta * cosTheta);                  // :52
     bool cannotRefract = eta * sinTheta > 1.0;                               // :53
     double reflectProb = schlick(cosTheta, eta);                             // :54

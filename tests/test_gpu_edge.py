@@ -100,3 +100,27 @@ def test_conservative_fp32_boxes_at_the_extremes(need_gpu, case):
                 L["intensity"] = list(np.asarray(L["intensity"], dtype=float) * s * s)
     spec.camera = cam
     check(*both(spec))
+
+
+@pytest.mark.parametrize("box_precision", [0, 1, 2])
+def test_nan_bounce_terms_follow_ghc_min_max(need_gpu, box_precision):
+    """Haskell's max / min on a NaN (Trace.hs:91-94 with GHC's Ord Double defaults): a NaN bounce term is clamped to 0, a path that
+    never hit anything is returned unclamped (NaN / inf primary misses stay NaN / inf).  Kernel = oracle, NaN positions included."""
+    import numpy as np
+    from nan_cases import nan_scene
+    from oracle import oracle as O
+    from raytracer_amd import api
+    spec = nan_scene()
+    o = O.OracleScene(spec)
+    ref = o.render()
+    o.close()
+    g = api.GpuScene(spec)
+    res, _ = g.render(box_precision=box_precision)
+    g.close()
+    assert np.isnan(ref["radiance"]).any() and np.isinf(ref["radiance"]).any()
+    assert (res["prim_id"] == ref["prim_id"]).all()
+    assert np.array_equal(np.isnan(res["radiance"]), np.isnan(ref["radiance"]))
+    assert np.array_equal(np.isinf(res["radiance"]), np.isinf(ref["radiance"]))
+    ok = np.isfinite(ref["radiance"])
+    assert np.abs(res["radiance"][ok] - ref["radiance"][ok]).max() <= 1e-12
+    assert (res["rgb8"] == ref["rgb8"]).all()
