@@ -34,7 +34,7 @@ raytracer_amd/lib/librtcore.so: $(CORE_SRC) $(CORE_HDR)
 # -ffp-contract=off: the BVH builder's sort keys must round exactly like the reference's doubles
 raytracer_amd/lib/librthost.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p raytracer_amd/lib
-	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -pthread $(HOST_SRC) -o $@
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -pthread $(HOST_SRC) -lz -o $@
 
 raytracer_amd/bin/rtcli: raytracer_amd/csrc/rtcli.cpp raytracer_amd/lib/librtcore.so raytracer_amd/lib/librthost.so
 	@mkdir -p raytracer_amd/bin

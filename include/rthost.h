@@ -65,9 +65,11 @@ typedef struct rth_config_view {
 } rth_config_view;
 int  rth_config_get(const rth_config *cfg, rth_config_view *view);
 
-/* loadSkySphere (app/Rendering/SkySphere.hs:18-29): ".hdr" (Radiance RGBE, flat or RLE) -> RT_SKY_RGBF,
- * binary/ASCII PPM (P6/P3, maxval 255) -> RT_SKY_RGB8.  The reference decodes more formats through
- * JuicyPixels (png/jpg/...); those return RT_ERR_UNSUPPORTED here.  Free pixels with rth_sky_free. */
+/* loadSkySphere (app/Rendering/SkySphere.hs:18-29): ".hdr" (Radiance RGBE, flat or RLE) -> RT_SKY_RGBF; any other file goes
+ * through readImage + convertRGB8 there: PNG (all colour types and depths, Adam7), uncompressed 24 / 32-bit BMP, true-colour /
+ * grey TGA, and binary / ASCII PPM (P6 / P3, maxval 255; not a JuicyPixels format: for tests) -> RT_SKY_RGB8, alpha dropped, grey
+ * replicated, 16-bit samples cut to their high byte.  JPEG, GIF and TIFF, which JuicyPixels also decodes, return
+ * RT_ERR_UNSUPPORTED.  Free pixels with rth_sky_free. */
 int  rth_sky_load(const char *path, int32_t *format, int32_t *width, int32_t *height, void **pixels);
 void rth_sky_free(void *pixels);
 

@@ -186,3 +186,128 @@ def test_edge_inputs_follow_the_reference(tmp_path):
     assert load(json.dumps(cfg)) != 0
     (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 0 0\nNi 1.5\nillum 7\n")
     assert load(json.dumps(cfg)) == 0
+
+
+def _load_ldr(path):
+    fmt, w, h, px = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+    F.check(F.host().rth_sky_load(str(path).encode(), C.byref(fmt), C.byref(w), C.byref(h), C.byref(px)), "host")
+    a = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 3)).copy()
+    F.host().rth_sky_free(px)
+    assert fmt.value == F.RT_SKY_RGB8
+    return a
+
+
+def _png_bytes(width, height, depth, ctype, rows, palette=None, interlace=False, filters=None):
+    """A PNG written by hand (zlib + CRCs): `rows` = per-scanline raw sample bytes of the WHOLE image; for Adam7 the seven
+    reduced images are cut out of it here (whole-byte pixels only); `filters` picks a filter type per scanline."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    nch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bpp = max(1, nch * depth // 8)
+
+    def filt(ft, cur, prev):
+        out = bytearray(len(cur))
+        for i, v in enumerate(cur):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 4:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            else:
+                pred = [0, a, b, (a + b) >> 1][ft]
+            out[i] = (v - pred) & 255
+        return bytes([ft]) + bytes(out)
+
+    def encode(img_rows):
+        raw, prev = b"", bytes(len(img_rows[0])) if img_rows else b""
+        for y, r in enumerate(img_rows):
+            ft = (filters[y % len(filters)] if filters else 0)
+            raw += filt(ft, r, prev)
+            prev = r
+        return raw
+
+    if not interlace:
+        raw = encode(rows)
+    else:
+        raw = b""
+        x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+        for p in range(7):
+            sub = [b"".join(rows[y][x * bpp:(x + 1) * bpp] for x in range(x0[p], width, dx[p])) for y in range(y0[p], height, dy[p])]
+            sub = [r for r in sub if r]
+            if sub:
+                raw += encode(sub)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette))
+    half = len(zlib.compress(raw)) // 2
+    z = zlib.compress(raw)
+    return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")      # two IDAT chunks: they concatenate
+
+
+def test_sky_loader_ldr_formats(tmp_path):
+    """SkySphere.hs:28-29: every non-.hdr sky goes through JuicyPixels' readImage + convertRGB8.  PNG, BMP and TGA files written
+    by Pillow (an independent encoder) and by a hand-made PNG writer (16-bit, Adam7, every filter type, low bit depths) must decode to
+    what convertRGB8 documents: alpha dropped, grey replicated, the HIGH byte of 16-bit samples, palettes expanded, 1/2/4-bit grey
+    scaled as i * 255 div (2^depth - 1).  (PARITY UNPINNED against JuicyPixels itself, like the .hdr rule.)"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    W, H = 19, 11
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (H, W, 1), dtype=np.uint8)], axis=2)
+    grey = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    # ---- Pillow-written files
+    Image.fromarray(rgb, "RGB").save(tmp_path / "a.png")
+    assert np.array_equal(_load_ldr(tmp_path / "a.png"), rgb)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "b.png")
+    assert np.array_equal(_load_ldr(tmp_path / "b.png"), rgb)                                  # alpha dropped, not blended
+    Image.fromarray(grey, "L").save(tmp_path / "c.png")
+    assert np.array_equal(_load_ldr(tmp_path / "c.png"), np.repeat(grey[:, :, None], 3, axis=2))
+    pal = Image.fromarray(rgb, "RGB").quantize(colors=16)                                      # 4-bit palette image
+    pal.save(tmp_path / "d.png")
+    assert np.array_equal(_load_ldr(tmp_path / "d.png"), np.asarray(pal.convert("RGB")))
+    one = Image.fromarray((grey > 127).astype(np.uint8) * 255, "L").convert("1")               # 1-bit grey
+    one.save(tmp_path / "e.png")
+    assert np.array_equal(_load_ldr(tmp_path / "e.png"), np.repeat(((grey > 127) * 255).astype(np.uint8)[:, :, None], 3, axis=2))
+    Image.fromarray(rgb, "RGB").save(tmp_path / "f.bmp")
+    assert np.array_equal(_load_ldr(tmp_path / "f.bmp"), rgb)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "g.bmp")
+    assert np.array_equal(_load_ldr(tmp_path / "g.bmp"), rgb)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "h.tga")
+    assert np.array_equal(_load_ldr(tmp_path / "h.tga"), rgb)
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "i.tga", compression="tga_rle")
+    assert np.array_equal(_load_ldr(tmp_path / "i.tga"), rgb)
+    Image.fromarray(grey, "L").save(tmp_path / "j.tga")
+    assert np.array_equal(_load_ldr(tmp_path / "j.tga"), np.repeat(grey[:, :, None], 3, axis=2))
+    # ---- hand-made PNGs: 16-bit RGB with every filter type; Adam7; 16-bit grey + alpha; 2-bit grey
+    v16 = rng.integers(0, 65536, (H, W, 3), dtype=np.uint16)
+    rows = [v16[y].astype(">u2").tobytes() for y in range(H)]
+    (tmp_path / "k.png").write_bytes(_png_bytes(W, H, 16, 2, rows, filters=[0, 1, 2, 3, 4]))
+    assert np.array_equal(_load_ldr(tmp_path / "k.png"), (v16 >> 8).astype(np.uint8))         # from16to8: the high byte
+    rows8 = [rgba[y].tobytes() for y in range(H)]
+    (tmp_path / "l.png").write_bytes(_png_bytes(W, H, 8, 6, rows8, interlace=True, filters=[4, 3, 1]))
+    assert np.array_equal(_load_ldr(tmp_path / "l.png"), rgb)
+    ga16 = rng.integers(0, 65536, (H, W, 2), dtype=np.uint16)
+    (tmp_path / "m.png").write_bytes(_png_bytes(W, H, 16, 4, [ga16[y].astype(">u2").tobytes() for y in range(H)], filters=[2, 4]))
+    assert np.array_equal(_load_ldr(tmp_path / "m.png"), np.repeat((ga16[:, :, :1] >> 8).astype(np.uint8), 3, axis=2))
+    g2 = rng.integers(0, 4, (H, W), dtype=np.uint8)
+    packed = []
+    for y in range(H):
+        bits = 0
+        row = bytearray((W * 2 + 7) // 8)
+        for x in range(W):
+            row[(2 * x) >> 3] |= int(g2[y, x]) << (6 - ((2 * x) & 7))
+        packed.append(bytes(row))
+    (tmp_path / "n.png").write_bytes(_png_bytes(W, H, 2, 0, packed, filters=[0, 2]))
+    assert np.array_equal(_load_ldr(tmp_path / "n.png"), np.repeat((g2.astype(np.int64) * 255 // 3).astype(np.uint8)[:, :, None], 3, axis=2))
+    # ---- what this host does not decode fails loudly
+    Image.fromarray(rgb, "RGB").save(tmp_path / "o.jpg")
+    fmt, w, h, px = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+    assert F.host().rth_sky_load(str(tmp_path / "o.jpg").encode(), C.byref(fmt), C.byref(w), C.byref(h), C.byref(px)) == F.RT_ERR_UNSUPPORTED
+    (tmp_path / "p.png").write_bytes((tmp_path / "a.png").read_bytes()[:60])
+    assert F.host().rth_sky_load(str(tmp_path / "p.png").encode(), C.byref(fmt), C.byref(w), C.byref(h), C.byref(px)) == F.RT_ERR_INVALID
