@@ -4,7 +4,7 @@ triangles, spheres (a few with negative or zero radius), planes of random point 
 glass / metal / emissive materials, point and directional lights, gradient / solid / LDR / HDR sky, thin lens, random
 leafThreshold / bvhMaxDepth / maxBounces, Russian roulette on some seeds; all three box_precision modes.
 Prints one line per seed; exit status 1 if any pixel's id differs or any radiance differs by more than 1e-12 (relative to
-max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme] [--axis]"""
+max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme] [--axis] [--nan]"""
 import os
 import sys
 
@@ -160,9 +160,24 @@ def scene_axis(seed):
     return spec, 0
 
 
+def scene_nan(seed):
+    """The standard family with what makes NaN and infinite radiance: an RGBF sky with infinite and NaN texels and a black
+    (attenuation 0) material on a third of the triangles - 0 x inf bounce terms, which the reference's clamp (GHC's max / min)
+    turns into 0, and non-finite primary misses, which it returns unclamped."""
+    spec, rr = scene(seed)
+    rng = np.random.default_rng(77_000_000 + seed)
+    img = scenes.sky_gradient_texture(w=48, h=24, fmt="rgbf")[1].copy()
+    m = rng.random(img.shape[:2])
+    img[m < 0.35] = np.inf
+    img[m > 0.9] = np.nan
+    spec.sky = ("rgbf", img)
+    spec.materials[0] = ("matte", {"diffuseColor": [0.0, 0.0, 0.0], "emissionColor": list(rng.uniform(0.0, 0.2, 3))})
+    return spec, rr
+
+
 def main():
-    big, extreme, axis = "--big" in sys.argv, "--extreme" in sys.argv, "--axis" in sys.argv
-    for f in ("--big", "--extreme", "--axis"):
+    big, extreme, axis, nan = "--big" in sys.argv, "--extreme" in sys.argv, "--axis" in sys.argv, "--nan" in sys.argv
+    for f in ("--big", "--extreme", "--axis", "--nan"):
         if f in sys.argv:
             sys.argv.remove(f)
     if len(sys.argv) > 2 and sys.argv[1] == "--seeds":
@@ -171,7 +186,7 @@ def main():
         seeds = range(*((int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)))
     bad = 0
     for seed in seeds:
-        spec, rr = scene_axis(seed) if axis else scene(seed, big, extreme)
+        spec, rr = scene_axis(seed) if axis else (scene_nan(seed) if nan else scene(seed, big, extreme))
         o = O.OracleScene(spec)
         ref = o.render(rr_start_bounce=rr, n_threads=min(16, os.cpu_count() or 8))
         o.close()
@@ -183,6 +198,8 @@ def main():
             with np.errstate(invalid="ignore"):
                 rel = np.abs(res["radiance"] - ref["radiance"]) / np.maximum(1.0, np.abs(ref["radiance"]))
             nan_mismatch = int((np.isnan(res["radiance"]) != np.isnan(ref["radiance"])).sum())
+            nan_mismatch += int((np.isposinf(res["radiance"]) != np.isposinf(ref["radiance"])).sum() + (np.isneginf(res["radiance"]) != np.isneginf(ref["radiance"])).sum())
+            rel = np.where(np.isfinite(ref["radiance"]) & np.isfinite(res["radiance"]), rel, 0.0)
             worst = float(np.nanmax(rel)) if np.isfinite(rel).any() else 0.0
             q = int((res["rgb8"] != ref["rgb8"]).sum())
             ok = ids == 0 and worst <= 1e-12 and nan_mismatch == 0 and q == 0
