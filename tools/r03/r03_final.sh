@@ -6,6 +6,8 @@ set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 280 --timeout-method thread > gpurun_out/r03_final_gpu.log 2>&1 || { tail -40 gpurun_out/r03_final_gpu.log; exit 1; }
 tail -1 gpurun_out/r03_final_gpu.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_smoke.log 2>&1 || { tail gpurun_out/r03_smoke.log; exit 1; }
+tail -1 gpurun_out/r03_smoke.log
 timeout -k 10 600 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err || { tail -20 gpurun_out/r03_bench.err; exit 1; }
 echo "bench ok"
 bash tools/profile.sh r03 --workload c4 > gpurun_out/r03_profile_c4.log 2>&1 || { tail -20 gpurun_out/r03_profile_c4.log; exit 1; }
