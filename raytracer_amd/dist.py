@@ -75,17 +75,21 @@ def untile_into(image: torch.Tensor, packed: torch.Tensor, width, height, rank, 
     return image
 
 
-def make_gather_buffers(packed: torch.Tensor, world) -> list:
-    """Rank 0's landing buffers of the gather as views of ONE contiguous (world, slots, C) tensor, so that the un-tiling of all
-    ranks is a single launch (rt_untile_all_bytes_device)."""
-    big = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    bufs = [big[r] for r in range(world)]
-    bufs[0]._rt_big = big                                # keeps the parent reachable from the list
-    return bufs
+class GatherBuffers(list):
+    """Rank 0's landing buffers of the gather: a list of per-rank tensors (what torch.distributed.gather takes) that are views
+    of ONE contiguous (world, slots, C) tensor `big`, so that the un-tiling of all ranks is a single launch."""
+
+    def __init__(self, big: torch.Tensor):
+        super().__init__(big[r] for r in range(big.shape[0]))
+        self.big = big
+
+
+def make_gather_buffers(packed: torch.Tensor, world) -> GatherBuffers:
+    return GatherBuffers(torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device))
 
 
 def _contiguous_parent(bufs, packed):
-    big = getattr(bufs[0], "_rt_big", None)
+    big = getattr(bufs, "big", None)
     if big is None or not big.is_cuda or big.shape[1:] != packed.shape or big.dtype != packed.dtype:
         return None
     return big

@@ -55,7 +55,9 @@ def worker_u8(rank, world, port, width, height, out_path):
         n_max = rdist.max_tiles(width, height, world)
         packed8 = (fill_packed(width, height, rank, world, n_max).abs() % 251).to(torch.uint8)
         frame = torch.full((height, width, 3), 9, dtype=torch.uint8) if rank == 0 else None
-        bufs = [torch.empty_like(packed8) for _ in range(world)] if rank == 0 else None
+        # bench.py's landing buffers: views of one contiguous tensor (a list subclass the collective must accept); on CPU tensors
+        # the un-tiling falls back to one scatter per rank
+        bufs = rdist.make_gather_buffers(packed8, world) if rank == 0 else None
         for _ in range(2):                                    # the buffers are reused frame after frame
             img = rdist.gather_frame(packed8, width, height, rank, world, image=frame, gather_buffers=bufs)
         if rank == 0:

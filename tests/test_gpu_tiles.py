@@ -81,16 +81,16 @@ def test_fused_eight_bit_tiles_and_one_launch_untile(need_gpu, world):
         g.render_tiles_device(rank, world, d_color=bufs[rank].data_ptr(), stream=stream)
     rgb8 = torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda")
     col = torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda")
-    F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs8[0]._rt_big.data_ptr()), n_max * 64 * 3,
+    F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs8.big.data_ptr()), n_max * 64 * 3,
                                                 C.c_void_p(rgb8.data_ptr()), 3, C.c_void_p(stream)))
-    F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs[0]._rt_big.data_ptr()), n_max * 64 * 24,
+    F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs.big.data_ptr()), n_max * 64 * 24,
                                                 C.c_void_p(col.data_ptr()), 24, C.c_void_p(stream)))
     torch.cuda.synchronize()
     g.close()
     assert np.array_equal(rgb8.cpu().numpy(), full["rgb8"])
     assert np.array_equal(col.cpu().numpy(), full["color"])
     with pytest.raises(F.RtError):                           # a stride that cannot hold a rank's tiles is refused on the host
-        F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs8[0]._rt_big.data_ptr()), 64, C.c_void_p(rgb8.data_ptr()), 3, None))
+        F.check(F.core().rt_untile_all_bytes_device(W, H, world, C.c_void_p(bufs8.big.data_ptr()), 64, C.c_void_p(rgb8.data_ptr()), 3, None))
 
 
 def test_quantize_device_matches_host_rule(need_gpu):
