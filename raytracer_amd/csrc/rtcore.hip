@@ -1108,9 +1108,10 @@ static int render_single(Replica *s, const rt_camera *cam, const rt_params *p, r
 
 // One frame on a device group (rt_init_devices): replica i renders the tiles of rank i of world N from its own copy of
 // the scene, on its own stream, driven by its own host thread; its packed tiles go to the group's device 0 as peer
-// copies (one xGMI link per peer, all at once: a gather, not a ring), are un-tiled there and leave for the host in one copy
-// per output.  When only the 8-bit frame is asked for, the replicas quantise first and 3 bytes per pixel cross xGMI
-// instead of 24.  The frame equals the single-device frame bit for bit (RNG keyed on the global pixel).
+// copies (one xGMI link per peer, all at once: a gather, not a ring) into ONE contiguous gather area per output, are un-tiled
+// there by one launch per output (k_untile_all) and leave for the host in one copy per output.  Every replica's k_resolve writes
+// the 8-bit form of its tiles itself, so the 8-bit frame crosses xGMI as 3 bytes per pixel and no quantise launch exists.
+// The frame equals the single-device frame bit for bit (RNG keyed on the global pixel).
 static int render_group(rt_scene *sc, const rt_camera *cam, const rt_params *p, rt_output *out, rt_stats *stats) {
   const int N = (int)sc->rep.size();
   const int W = p->width, H = p->height;
