@@ -352,12 +352,27 @@ inline V3 backgroundColor(const Scene &s, const Ray &ray) {
   return lerp(tval, s.bg2, s.bg1);                                 // :135  Col.lerp tval c2 c1
 }
 
+// atan2 on Double under GHC (SkySphere.hs:35 calls it): instance RealFloat Double does not define atan2, so the class DEFAULT of
+// GHC.Float runs - the Haskell 2010 report's Prelude definition, restated guard by guard - and libm's atan2 is never called.
+// It differs from libm's in the last bits (the division, atan and `pi + ...` each round), which decides the texel of a direction
+// within rounding of a texel boundary.  atan on Double is libm's atan.
+inline bool isNegativeZero(double v) { return v == 0.0 && std::signbit(v); }
+inline double hsAtan2(double y, double x) {
+  if (x > 0) return std::atan(y / x);
+  if (x == 0 && y > 0) return M_PI / 2;
+  if (x < 0 && y > 0) return M_PI + std::atan(y / x);
+  if ((x <= 0 && y < 0) || (x < 0 && isNegativeZero(y)) || (isNegativeZero(x) && isNegativeZero(y))) return -hsAtan2(-y, x);
+  if (y == 0 && (x < 0 || isNegativeZero(x))) return M_PI;   // must be after the previous test on zero y
+  if (x == 0 && y == 0) return y;                            // must be after the other double zero tests
+  return x + y;                                              // x or y is a NaN
+}
+
 // sampleSkySphere, Rendering/SkySphere.hs:32-50
 inline int clampInt(long v, int lo, int hi) { return (int)std::max((long)lo, std::min(v, (long)hi)); }
 inline V3 sampleSkySphere(const Sky &sky, V3 dir) {
   V3 d = normalize(dir);                                                     // :34
   double dy = std::max(-1.0, std::min(1.0, d.y));   // guard: reference would take asin of 1+ulp (NaN -> garbage index)
-  double u = 0.5 + std::atan2(d.z, d.x) / (2 * M_PI);                        // :35
+  double u = 0.5 + hsAtan2(d.z, d.x) / (2 * M_PI);                           // :35
   double v = 0.5 - std::asin(dy) / M_PI;                                     // :36
   int i = clampInt((long)std::floor(u * (double)sky.w), 0, sky.w - 1);       // :39
   int j = clampInt((long)std::floor(v * (double)sky.h), 0, sky.h - 1);       // :40

@@ -239,6 +239,25 @@ def schlick(cosine, ref_idx):
     return r0sq + (1 - r0sq) * ((1 - cosine) ** 5)
 
 
+def hs_atan2(y, x):
+    """atan2 on Double under GHC: the RealFloat class DEFAULT (GHC.Float; the Haskell 2010 report's Prelude definition) - instance
+    RealFloat Double does not define atan2, so libm's atan2 is never called: division, atan and `pi + ...` each round."""
+    neg_zero = lambda v: v == 0.0 and math.copysign(1.0, v) < 0
+    if x > 0:
+        return math.atan(y / x)
+    if x == 0 and y > 0:
+        return math.pi / 2
+    if x < 0 and y > 0:
+        return math.pi + math.atan(y / x)
+    if (x <= 0 and y < 0) or (x < 0 and neg_zero(y)) or (neg_zero(x) and neg_zero(y)):
+        return -hs_atan2(-y, x)
+    if y == 0 and (x < 0 or neg_zero(x)):
+        return math.pi
+    if x == 0 and y == 0:
+        return y
+    return x + y
+
+
 def hs_min(x, y): return x if x <= y else y          # GHC.Classes defaults of Ord Double: NOT Python's min / max on a NaN
 def hs_max(x, y): return y if x <= y else x
 def clamp3(v, lo, hi): return tuple(hs_max(lo, hs_min(hi, x)) for x in v)   # Trace.hs:91-94: cl v = max lo (min hi v)
@@ -390,7 +409,7 @@ def scene_from_spec(spec):
 
         def background(ray):                                           # sampleSkySphere, Rendering/SkySphere.hs:32-47
             dx, dy, dz = normalize(ray[1])
-            u = 0.5 + math.atan2(dz, dx) / (2 * math.pi)
+            u = 0.5 + hs_atan2(dz, dx) / (2 * math.pi)
             v = 0.5 - math.asin(dy) / math.pi
             i = max(0, min(int(math.floor(u * float(sw))), sw - 1))
             j = max(0, min(int(math.floor(v * float(sh))), sh - 1))

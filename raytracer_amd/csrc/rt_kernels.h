@@ -13,6 +13,7 @@
 #pragma once
 #include "rt_device.h"
 #include "../../include/rtcore.h"
+#include "rt_sky_tables.h"
 
 struct KScene {
   const void *nodes;           // DNode<BT>[] of the tree the kernel traverses
@@ -33,7 +34,8 @@ struct KScene {
   const double *shade_recs;
   const void *sky;
   const double *sky_u_tab;     // (cos phi_k, sin phi_k), phi_k = 2 pi (k / w - 0.5), k = -2 .. w + 2: the texel columns' boundary directions
-  const double *sky_v_tab;     // cos(pi k / h), k = -2 .. h + 2 (+inf below 0, -inf above h): the texel rows' thresholds on y
+  const double *sky_v_tab;     // T_k, k = -2 .. h + 2 (+inf up to 0, -inf above h): the largest y the reference puts in a row >= k (rt_sky_tables.h)
+  const double *sky_u_q;       // Q_k[3]: per column boundary and region of (x, z), the smallest z / x the reference puts in a column >= k (rt_sky_tables.h)
   int32_t root_ref;
   int32_t ref_root_ref;        // root of the reference's tree (== root_ref unless FAST)
   int32_t n_lights;
@@ -78,7 +80,7 @@ enum { STAT_CLOSEST = 0, STAT_SHADOW, STAT_NODES, STAT_TRI, STAT_SPHERE, STAT_PL
        STAT_COUNT };
 
 // cold code (once per path, not per traversal step).  Inlined: taking KScene/KFrame by reference out of line cost more
-// scratch than it saved registers; only the libm-heavy leaves (sky_uv, pow_gamma) are real calls.
+// scratch than it saved registers; only the libm-heavy leaves (sky_texel_exact, pow_gamma) are real calls.
 #define RT_COLD __device__ __forceinline__
 
 #define RT_TMIN 0.001
@@ -111,31 +113,69 @@ RT_COLD void camera_ray(const KFrame &fr, int px, int py, uint32_t pixel, uint32
   d = normalize3(dir);                                              // :60
 }
 
-// equirect coordinates of a unit direction (SkySphere.hs:35-36).  Kept OUT of line on purpose: the FP64 atan2/asin
-// bodies need ~100 temporaries, which would otherwise set the register allocation of the whole render kernel.
-__device__ RT_NOINLINE double2 sky_uv(double nx, double ny, double nz) {
-  const double dy = fmax(-1.0, fmin(1.0, ny));
-  double2 r;
-  r.x = 0.5 + atan2(nz, nx) / (2 * 3.14159265358979323846);
-  r.y = 0.5 - asin(dy) / 3.14159265358979323846;
-  return r;
+#define SKY_NEAR_BOUNDARY 1.6e-14   // |cross product| below which a column is decided by its quotient z / x; the pipeline's rounding is worth ~3e-15
+#define SKY_TAB_PAD 2      // the tables start at k = -SKY_TAB_PAD
+
+// GHC's atan2 on Double: the RealFloat class default of GHC.Float (the Haskell 2010 report's definition; instance RealFloat
+// Double does not override it), NOT libm's atan2 - it differs from it in the last bits (division, atan and pi + ... each round).
+__device__ inline double hs_atan2(double y, double x) {
+  const double pi = 3.14159265358979323846;
+  if (x > 0.0) return atan(y / x);
+  if (x == 0.0 && y > 0.0) return pi / 2;
+  if (x < 0.0 && y > 0.0) return pi + atan(y / x);
+  const bool nzy = y == 0.0 && signbit(y), nzx = x == 0.0 && signbit(x);
+  if ((x <= 0.0 && y < 0.0) || (x < 0.0 && nzy) || (nzx && nzy)) {   // = -atan2 (-y) x, whose guards are the three above and `pi`
+    const double ny = -y;
+    return -(x == 0.0 && ny > 0.0 ? pi / 2 : (x < 0.0 && ny > 0.0 ? pi + atan(ny / x) : pi));
+  }
+  if (y == 0.0 && (x < 0.0 || nzx)) return pi;
+  if (x == 0.0 && y == 0.0) return y;
+  return x + y;
 }
 
-// Texel of a unit direction (SkySphere.hs:35-41): i = clamp(floor(u w)), j = clamp(floor(v h)) with u = 0.5 + atan2(z, x) / 2pi,
+// The reference's texel for ANY direction, the slow way - for the lanes sky_texel's table tests cannot settle (a direction within
+// rounding of a column boundary, a zero x or z, a failed estimate).  ONE out-of-line call with few arguments, so that the FP64
+// atan / asin bodies (~100 temporaries) and the FP64 division do not set the register allocation of the render kernel.
+// Column: the reference's own expression (SkySphere.hs:35,39) with ocml's atan is right to within one column; which of the
+// three it is, is decided the way the reference's roundings decide it, by comparing z / x with the thresholds of boundaries i and
+// i + 1 (skytab::side_q, rt_sky_tables.h).  With a zero x or z (atan2's other guards; they give exact multiples of pi / 2) or at
+// the +-pi cut (no table entry; the column saturates at 0 / w - 1) the expression's value stands.  Row: likewise, against T_k.
+__device__ RT_NOINLINE int2 sky_texel_exact(const double *u_q, const double *v_tab, int w, int h, double x, double y, double z) {
+  const double dy = fmax(-1.0, fmin(1.0, y));
+  const double u = 0.5 + hs_atan2(z, x) / (2 * 3.14159265358979323846);   // :35
+  const double v = 0.5 - asin(dy) / 3.14159265358979323846;               // :36
+  long long i = (long long)floor(u * (double)w), j = (long long)floor(v * (double)h);
+  i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+  j = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+  {
+    const double *Q = u_q + 3 * ((int)i + SKY_TAB_PAD);
+    const int s0 = i >= 1 ? skytab::side_q(Q, x, z) : 1, s1 = i + 1 <= w - 1 ? skytab::side_q(Q + 3, x, z) : 0;
+    if (s0 >= 0 && s1 >= 0) i = i - 1 + s0 + s1;
+  }
+  if (dy == dy) {
+    const double *T = v_tab + ((int)j + SKY_TAB_PAD);
+    j = j - 1 + (dy <= T[0] ? 1 : 0) + (dy <= T[1] ? 1 : 0);
+  }
+  i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+  j = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
+  return make_int2((int)i, (int)j);
+}
+
+// Texel of a unit direction (SkySphere.hs:35-41): i = clamp(floor(u w)), j = clamp(floor(v h)) with u = 0.5 + atan2 z x / 2pi,
 // v = 0.5 - asin(y) / pi.  Only the INTEGERS matter, so the two FP64 libm calls (~400 VALU instructions, once per path) are
-// replaced by their inverse on the host: floor(v h) >= k  <=>  y <= cos(pi k / h), and floor(u w) >= k  <=>  the direction
-// (x, z) lies counter-clockwise of the boundary direction (cos phi_k, sin phi_k), phi_k = 2pi (k / w - 0.5), i.e.
-// cos phi_k * z - sin phi_k * x >= 0 - valid while the two are less than pi apart.  A cheap FP32 estimate gives the texel
-// to within one; four exact FP64 threshold tests around it (tables sky_v_tab / sky_u_tab, built at upload) give the texel.
-// A direction within ~1e-16 of a texel boundary may fall on the other side than libm's rounding puts it - the same class of
-// difference as between two libm implementations (ocml here, glibc under GHC).  If the estimate is ever off by more than
-// one texel (or NaN), the bracketing tests fail and the lane takes the libm path (sky_uv).
-#define SKY_NEAR_BOUNDARY 4e-15
-#define SKY_TAB_PAD 2      // the tables start at k = -SKY_TAB_PAD
-RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
-  const int w = sc.sky_w, h = sc.sky_h;
+// replaced by their inverse, tabulated on the host at upload (rt_sky_tables.h):
+//   rows     floor(v h) >= k  <=>  y <= T_k, T_k the largest DOUBLE for which the reference's expression (with the host's asin)
+//            gives a row >= k: exact for every y, boundary or not;
+//   columns  floor(u w) >= k  <=>  the direction (x, z) lies counter-clockwise of the boundary direction (cos phi_k, sin phi_k),
+//            phi_k = 2pi (k / w - 0.5), i.e. cos phi_k z - sin phi_k x >= 0 (valid while the two are less than pi apart) - unless the
+//            direction is within rounding of the boundary, where the reference's texel is decided by how the division, atan, the
+//            sums and the product of GHC's atan2 and of u w round: there sky_texel_exact compares z / x with the boundary's threshold Q_k.
+// A cheap FP32 estimate gives the texel to within one; four threshold tests around it give the texel.  If the estimate is ever off
+// by more than one texel (or NaN), or the direction has a zero x or z or is at the +-pi cut, the lane evaluates the reference's
+// expressions themselves (sky_texel_exact).
+RT_COLD void sky_texel(const double *u_tab, const double *u_q, const double *v_tab, int w, int h, d3 n, int &i, int &j) {
   const double dy = fmax(-1.0, fmin(1.0, n.y));
-  bool ok = true;
+  int bits, i0;
   {                                                                 // ---- column: FP32 estimate of atan2(z, x)
     const float x = (float)n.x, z = (float)n.z, ax = fabsf(x), az = fabsf(z);
     const float mx = fmaxf(ax, az), mn = fminf(ax, az);
@@ -144,20 +184,20 @@ RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
     r = az > ax ? 1.57079637f - r : r;
     r = x < 0.0f ? 3.14159274f - r : r;
     r = z < 0.0f ? -r : r;
-    int i0 = (int)floorf((0.5f + r * 0.159154943f) * (float)w);
+    i0 = (int)floorf((0.5f + r * 0.159154943f) * (float)w);
     i0 = i0 < 0 ? 0 : (i0 > w - 1 ? w - 1 : i0);
-    const double2 *t = (const double2 *)sc.sky_u_tab + (i0 - 1 + SKY_TAB_PAD);          // boundaries i0-1 .. i0+2
+    const double2 *t = (const double2 *)u_tab + (i0 - 1 + SKY_TAB_PAD);          // boundaries i0-1 .. i0+2
     const double2 b0 = t[0], b1 = t[1], b2 = t[2], b3 = t[3];
     const double v1 = b1.x * n.z - b1.y * n.x, v2 = b2.x * n.z - b2.y * n.x;
-    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c1 = v1 >= 0.0;
-    const bool c2 = v2 >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
-    ok = ok && c0 && !c3 && n.z != 0.0 && (mx == mx) && mx > 0.0f;   // z = +-0: atan2 tells +pi from -pi by the sign of zero, a cross product cannot
-    // A direction within rounding of a boundary belongs to whichever texel the reference's FLOATING-POINT u = 0.5 + atan2 / 2 pi falls
-    // into, not to the one exact geometry says: the lane takes the libm path.  This is not a measure-zero corner: a camera that looks
-    // exactly along an axis has a centre column of rays with x or z = +-1e-16 (rounding residue), and x = +-z on its diagonals
-    // (tools/fuzz_oracle.py --extreme).  u carries ~1 ulp of 1 = 1.1e-16, i.e. 7e-16 in angle.
-    ok = ok && fabs(v1) > SKY_NEAR_BOUNDARY && fabs(v2) > SKY_NEAR_BOUNDARY;
-    i = (long long)i0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
+    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
+    // zeros: atan2's other guards (+pi or -pi by the sign of a zero ...), which a cross product cannot see
+    const bool ok = c0 && !c3 && n.z != 0.0 && n.x != 0.0 && (mx == mx) && mx > 0.0f;
+    // A direction within rounding of a boundary belongs to whichever texel the reference's FLOATING-POINT u w falls into, not to the
+    // one exact geometry says.  This is not a measure-zero corner: a camera that looks exactly along an axis has a centre column of
+    // rays with x or z = +-1e-16 (rounding residue), and x = +-z on its diagonals (tools/fuzz_oracle.py --extreme,
+    // tools/sky_boundary_probe.py).
+    bits = (v1 >= 0.0 ? 1 : 0) | (v2 >= 0.0 ? 2 : 0) | (fabs(v1) <= SKY_NEAR_BOUNDARY ? 4 : 0) | (fabs(v2) <= SKY_NEAR_BOUNDARY ? 8 : 0) | (ok ? 16 : 0);
+    i = i0 - 1 + (bits & 1) + ((bits >> 1) & 1);
   }
   {                                                                 // ---- row: FP32 estimate of asin(y) (Abramowitz-Stegun 4.4.45)
     const float y = (float)dy, ay = fabsf(y);
@@ -166,26 +206,37 @@ RT_COLD void sky_texel(const KScene &sc, d3 n, long long &i, long long &j) {
     p = y < 0.0f ? -p : p;
     int j0 = (int)floorf((0.5f - p * 0.318309886f) * (float)h);
     j0 = j0 < 0 ? 0 : (j0 > h - 1 ? h - 1 : j0);
-    const double *t = sc.sky_v_tab + (j0 - 1 + SKY_TAB_PAD);                            // thresholds j0-1 .. j0+2
+    const double *t = v_tab + (j0 - 1 + SKY_TAB_PAD);                            // thresholds j0-1 .. j0+2
     const bool c0 = dy <= t[0], c1 = dy <= t[1], c2 = dy <= t[2], c3 = dy <= t[3];
-    ok = ok && c0 && (!c3 || j0 + 2 > h);                           // (dy = -1 reaches the last threshold: clamped below)
-    ok = ok && fabs(dy - t[1]) > SKY_NEAR_BOUNDARY && fabs(dy - t[2]) > SKY_NEAR_BOUNDARY;   // as for the column: v = 0.5 - asin / pi carries ~1e-16
-    j = (long long)j0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
+    if (!(c0 && (!c3 || j0 + 2 > h))) bits &= ~16;                  // (dy = -1 reaches the last threshold: clamped below)
+    j = j0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
   }
-  if (!ok) {                                                        // never on a valid estimate; keeps the result defined
-    const double2 uv = sky_uv(n.x, n.y, n.z);
-    i = (long long)floor(uv.x * (double)w); j = (long long)floor(uv.y * (double)h);
+  if (bits < 16 || (bits & 12)) {                                   // rare: see sky_texel_exact
+    const int2 r = sky_texel_exact(u_q, v_tab, w, h, n.x, n.y, n.z);
+    i = r.x; j = r.y;
   }
   i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
   j = j < 0 ? 0 : (j > h - 1 ? h - 1 : j);
 }
 
+#ifdef RT_SKY_OOL   // experiment: the whole lookup out of line
+__device__ RT_NOINLINE int2 sky_texel_ool(const double *u_tab, const double *u_q, const double *v_tab, int w, int h, double x, double y, double z) {
+  int i, j;
+  sky_texel(u_tab, u_q, v_tab, w, h, mk3(x, y, z), i, j);
+  return make_int2(i, j);
+}
+#endif
+
 // ---------------------------------------------------------------- background (Trace.hs:78-83)
 RT_COLD d3 background(const KScene &sc, d3 dir) {
   if (sc.sky_format != RT_SKY_NONE) {                               // SkySphere.hs:32-47
     d3 n = normalize3(dir);
-    long long i, j;
-    sky_texel(sc, n, i, j);
+    int i, j;
+#ifdef RT_SKY_OOL
+    { const int2 r = sky_texel_ool(sc.sky_u_tab, sc.sky_u_q, sc.sky_v_tab, sc.sky_w, sc.sky_h, n.x, n.y, n.z); i = r.x; j = r.y; }
+#else
+    sky_texel(sc.sky_u_tab, sc.sky_u_q, sc.sky_v_tab, sc.sky_w, sc.sky_h, n, i, j);
+#endif
     size_t k = ((size_t)j * sc.sky_w + (size_t)i) * 3;
     if (sc.sky_format == RT_SKY_RGB8) {
       const uint8_t *p = (const uint8_t *)sc.sky;

@@ -161,7 +161,7 @@ struct HostScene {
   std::vector<DMaterial> mats;
   std::vector<DLight> lights;
   std::vector<double> plane_boxes, tri_normals;
-  std::vector<double> sky_u_tab, sky_v_tab;   // texel boundaries of the sky lookup (sky_texel, rt_kernels.h)
+  std::vector<double> sky_u_tab, sky_u_q, sky_v_tab;   // texel boundaries of the sky lookup (sky_texel, rt_kernels.h)
   const void *sky = nullptr;
   size_t sky_bytes = 0;
   bool has_fast = false;
@@ -189,7 +189,7 @@ struct Replica {
   double *d_plane_boxes = nullptr;
   double *d_tri_normals = nullptr;
   void *d_sky = nullptr;
-  double *d_sky_u_tab = nullptr, *d_sky_v_tab = nullptr;
+  double *d_sky_u_tab = nullptr, *d_sky_u_q = nullptr, *d_sky_v_tab = nullptr;
   KScene ks{};
   int n_internal = 0, depth = 0;
   bool has_boxed_planes = false;        // some plane sits in a non-root leaf: its visibility can depend on the reference's traversal (literal_hit)
@@ -230,7 +230,7 @@ static void replica_destroy(Replica *s) {
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
   (void)hipFree(s->d_fnodes32); (void)hipFree(s->d_fprims); (void)hipFree(s->d_ref_anc); (void)hipFree(s->d_ref_depth); (void)hipFree(s->d_leaf_anc);
-  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky); (void)hipFree(s->d_sky_u_tab); (void)hipFree(s->d_sky_v_tab);
+  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky); (void)hipFree(s->d_sky_u_tab); (void)hipFree(s->d_sky_u_q); (void)hipFree(s->d_sky_v_tab);
   (void)hipFree(s->ws.counter); (void)hipFree(s->ws.stats); (void)hipFree(s->ws.fscratch); (void)hipFree(s->ws.samples); (void)hipFree(s->ws.tiles);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
   if (s->p_color != s->g_color) { (void)hipFree(s->p_color); (void)hipFree(s->p_radiance); (void)hipFree(s->p_primid); (void)hipFree(s->p_rgb8); }
@@ -563,17 +563,7 @@ static int prepare_host_scene(const rt_scene_desc *d, HostScene &hs) {
 
   hs.sky = d->sky_pixels;
   if (d->sky_format != RT_SKY_NONE) {
-    const int w = d->sky_width, h = d->sky_height;
-    const double pi = 3.14159265358979323846;
-    hs.sky_u_tab.resize(2 * (size_t)(w + 2 * SKY_TAB_PAD + 1));
-    for (int k = -SKY_TAB_PAD; k <= w + SKY_TAB_PAD; ++k) {
-      const double phi = 2 * pi * ((double)k / (double)w - 0.5);
-      hs.sky_u_tab[2 * (size_t)(k + SKY_TAB_PAD)] = std::cos(phi);
-      hs.sky_u_tab[2 * (size_t)(k + SKY_TAB_PAD) + 1] = std::sin(phi);
-    }
-    hs.sky_v_tab.resize((size_t)(h + 2 * SKY_TAB_PAD + 1));
-    for (int k = -SKY_TAB_PAD; k <= h + SKY_TAB_PAD; ++k)
-      hs.sky_v_tab[(size_t)(k + SKY_TAB_PAD)] = k < 0 ? INFINITY : (k > h ? -INFINITY : (k == 0 ? 1.0 : (k == h ? -1.0 : std::cos(pi * (double)k / (double)h))));
+    skytab::build(d->sky_width, d->sky_height, SKY_TAB_PAD, hs.sky_u_tab, hs.sky_u_q, hs.sky_v_tab);   // rt_sky_tables.h
   }
   hs.sky_bytes = d->sky_format == RT_SKY_NONE ? 0 : (size_t)d->sky_width * d->sky_height * 3 * (d->sky_format == RT_SKY_RGB8 ? 1 : 4);
   KScene &k = hs.ks;
@@ -617,6 +607,7 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
     UP(dev_upload(&p, (const uint8_t *)hs.sky, hs.sky_bytes));
     s->d_sky = p;
     UP(dev_upload(&s->d_sky_u_tab, hs.sky_u_tab.data(), hs.sky_u_tab.size()));
+    UP(dev_upload(&s->d_sky_u_q, hs.sky_u_q.data(), hs.sky_u_q.size()));
     UP(dev_upload(&s->d_sky_v_tab, hs.sky_v_tab.data(), hs.sky_v_tab.size()));
   }
   uint32_t zero = 0;
@@ -630,7 +621,7 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
   k.nodes = s->d_nodes32; k.prims = s->d_prims; k.tprims = s->d_prims;
   k.ref_nodes64 = s->d_nodes64; k.ref_anc = s->d_ref_anc; k.ref_depth = s->d_ref_depth; k.leaf_anc = s->d_leaf_anc;
   k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
-  k.plane_boxes = s->d_plane_boxes; k.shade_recs = s->d_tri_normals; k.sky = s->d_sky; k.sky_u_tab = s->d_sky_u_tab; k.sky_v_tab = s->d_sky_v_tab;
+  k.plane_boxes = s->d_plane_boxes; k.shade_recs = s->d_tri_normals; k.sky = s->d_sky; k.sky_u_tab = s->d_sky_u_tab; k.sky_u_q = s->d_sky_u_q; k.sky_v_tab = s->d_sky_v_tab;
   *out = s;
   return RT_OK;
 }

@@ -11,6 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O                     # noqa: E402
+from oracle.pyref import hs_atan2                  # noqa: E402
 from raytracer_amd import _ffi as F                # noqa: E402
 from raytracer_amd import api, scenes              # noqa: E402
 
@@ -40,9 +41,8 @@ def directions(cam):
     return d / np.sqrt((d * d).sum(-1))[..., None]
 
 
-def main():
-    sw = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-    sh = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+def probe(sw, sh, steps=(1e-18, 1e-17, 1e-16, 1e-15, 1e-14, 1e-13), verbose=True):
+    """(differing pixels, pixels compared) over all boundary cases of a sw x sh sky"""
     rng = np.random.default_rng(5)
     img = rng.uniform(0.1, 1.0, size=(sh, sw, 3)).astype(np.float32)
     spec = scenes.c2_spheres(width=W, height=H, spp=1, max_bounces=0)
@@ -67,22 +67,29 @@ def main():
             cases.append((f"row {k} phi {phi}", c, t, (-math.sin(phi), 0.0, math.cos(phi))))
     bad = total = 0
     for name, c, t, s in cases:
-        for step in (1e-18, 1e-17, 1e-16, 1e-15, 1e-14, 1e-13):
+        for step in steps:
             cam = sweep_camera(c, t, s, step)
             ref = o.render(camera=cam, n_threads=8)["radiance"]
             res, _ = g.render(camera=cam, want=("radiance",))
             diff = np.argwhere((res["radiance"] != ref).any(-1))
             total += W * H
-            if len(diff):
-                bad += len(diff)
+            bad += len(diff)
+            if len(diff) and verbose:
                 d = directions(cam)
                 print(f"{name} step {step:g}: {len(diff)} of {W * H} pixels differ")
                 for py, px in diff[:6]:
                     x, y, z = d[py, px]
-                    u = 0.5 + math.atan2(z, x) / (2 * math.pi)
+                    u = 0.5 + hs_atan2(z, x) / (2 * math.pi)
                     v = 0.5 - math.asin(max(-1.0, min(1.0, y))) / math.pi
                     print(f"    px {px} py {py} d ({x!r}, {y!r}, {z!r})  u w {u * sw!r}  v h {v * sh!r}")
     o.close(); g.close()
+    return bad, total
+
+
+def main():
+    sw = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    sh = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    bad, total = probe(sw, sh)
     print(f"sky boundary probe {sw}x{sh}: {bad} of {total} pixels differ")
     return 1 if bad else 0
 
