@@ -140,7 +140,9 @@ __device__ inline double hs_atan2(double y, double x) {
 // three it is, is decided the way the reference's roundings decide it, by comparing z / x with the thresholds of boundaries i and
 // i + 1 (skytab::side_q, rt_sky_tables.h).  With a zero x or z (atan2's other guards; they give exact multiples of pi / 2) or at
 // the +-pi cut (no table entry; the column saturates at 0 / w - 1) the expression's value stands.  Row: likewise, against T_k.
-__device__ RT_NOINLINE int2 sky_texel_exact(const double *u_q, const double *v_tab, int w, int h, double x, double y, double z) {
+__device__ RT_NOINLINE int2 sky_texel_exact(const double *u_q, double x, double y, double z) {
+  const int w = (int)u_q[-2], h = (int)u_q[-1];                           // one table: (w, h), Q_k[3] ..., T_k ...  (rtcore.hip)
+  const double *v_tab = u_q + 3 * (w + 2 * SKY_TAB_PAD + 1);
   const double dy = fmax(-1.0, fmin(1.0, y));
   const double u = 0.5 + hs_atan2(z, x) / (2 * 3.14159265358979323846);   // :35
   const double v = 0.5 - asin(dy) / 3.14159265358979323846;               // :36
@@ -175,7 +177,7 @@ __device__ RT_NOINLINE int2 sky_texel_exact(const double *u_q, const double *v_t
 // expressions themselves (sky_texel_exact).
 RT_COLD void sky_texel(const double *u_tab, const double *u_q, const double *v_tab, int w, int h, d3 n, int &i, int &j) {
   const double dy = fmax(-1.0, fmin(1.0, n.y));
-  int bits, i0;
+  bool ok = true;
   {                                                                 // ---- column: FP32 estimate of atan2(z, x)
     const float x = (float)n.x, z = (float)n.z, ax = fabsf(x), az = fabsf(z);
     const float mx = fmaxf(ax, az), mn = fminf(ax, az);
@@ -184,20 +186,21 @@ RT_COLD void sky_texel(const double *u_tab, const double *u_q, const double *v_t
     r = az > ax ? 1.57079637f - r : r;
     r = x < 0.0f ? 3.14159274f - r : r;
     r = z < 0.0f ? -r : r;
-    i0 = (int)floorf((0.5f + r * 0.159154943f) * (float)w);
+    int i0 = (int)floorf((0.5f + r * 0.159154943f) * (float)w);
     i0 = i0 < 0 ? 0 : (i0 > w - 1 ? w - 1 : i0);
-    const double2 *t = (const double2 *)u_tab + (i0 - 1 + SKY_TAB_PAD);          // boundaries i0-1 .. i0+2
+    const double2 *t = (const double2 *)u_tab + (i0 - 1 + SKY_TAB_PAD);                 // boundaries i0-1 .. i0+2
     const double2 b0 = t[0], b1 = t[1], b2 = t[2], b3 = t[3];
     const double v1 = b1.x * n.z - b1.y * n.x, v2 = b2.x * n.z - b2.y * n.x;
-    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
+    const bool c0 = b0.x * n.z - b0.y * n.x >= 0.0, c1 = v1 >= 0.0;
+    const bool c2 = v2 >= 0.0, c3 = b3.x * n.z - b3.y * n.x >= 0.0;
     // zeros: atan2's other guards (+pi or -pi by the sign of a zero ...), which a cross product cannot see
-    const bool ok = c0 && !c3 && n.z != 0.0 && n.x != 0.0 && (mx == mx) && mx > 0.0f;
+    ok = ok && c0 && !c3 && n.z != 0.0 && n.x != 0.0 && (mx == mx) && mx > 0.0f;
     // A direction within rounding of a boundary belongs to whichever texel the reference's FLOATING-POINT u w falls into, not to the
     // one exact geometry says.  This is not a measure-zero corner: a camera that looks exactly along an axis has a centre column of
     // rays with x or z = +-1e-16 (rounding residue), and x = +-z on its diagonals (tools/fuzz_oracle.py --extreme,
-    // tools/sky_boundary_probe.py).
-    bits = (v1 >= 0.0 ? 1 : 0) | (v2 >= 0.0 ? 2 : 0) | (fabs(v1) <= SKY_NEAR_BOUNDARY ? 4 : 0) | (fabs(v2) <= SKY_NEAR_BOUNDARY ? 8 : 0) | (ok ? 16 : 0);
-    i = i0 - 1 + (bits & 1) + ((bits >> 1) & 1);
+    // tools/sky_boundary_probe.py).  Such a lane asks sky_texel_exact.
+    ok = ok && fabs(v1) > SKY_NEAR_BOUNDARY && fabs(v2) > SKY_NEAR_BOUNDARY;
+    i = i0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
   }
   {                                                                 // ---- row: FP32 estimate of asin(y) (Abramowitz-Stegun 4.4.45)
     const float y = (float)dy, ay = fabsf(y);
@@ -206,13 +209,13 @@ RT_COLD void sky_texel(const double *u_tab, const double *u_q, const double *v_t
     p = y < 0.0f ? -p : p;
     int j0 = (int)floorf((0.5f - p * 0.318309886f) * (float)h);
     j0 = j0 < 0 ? 0 : (j0 > h - 1 ? h - 1 : j0);
-    const double *t = v_tab + (j0 - 1 + SKY_TAB_PAD);                            // thresholds j0-1 .. j0+2
+    const double *t = v_tab + (j0 - 1 + SKY_TAB_PAD);                                   // thresholds j0-1 .. j0+2
     const bool c0 = dy <= t[0], c1 = dy <= t[1], c2 = dy <= t[2], c3 = dy <= t[3];
-    if (!(c0 && (!c3 || j0 + 2 > h))) bits &= ~16;                  // (dy = -1 reaches the last threshold: clamped below)
+    ok = ok && c0 && (!c3 || j0 + 2 > h);                           // (dy = -1 reaches the last threshold: clamped below)
     j = j0 - 1 + (c1 ? 1 : 0) + (c2 ? 1 : 0);
   }
-  if (bits < 16 || (bits & 12)) {                                   // rare: see sky_texel_exact
-    const int2 r = sky_texel_exact(u_q, v_tab, w, h, n.x, n.y, n.z);
+  if (!ok) {                                                        // rare: see sky_texel_exact
+    const int2 r = sky_texel_exact(u_q, n.x, n.y, n.z);
     i = r.x; j = r.y;
   }
   i = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);

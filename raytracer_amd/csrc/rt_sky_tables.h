@@ -35,7 +35,7 @@
 
 namespace skytab {
 
-// The device's test for a direction within rounding of column boundary k (sky_texel_cold, rt_kernels.h; here so that a host test runs
+// The device's test for a direction within rounding of column boundary k (sky_texel_exact, rt_kernels.h; here so that a host test runs
 // the same lines): does the reference put (x, z) in a column >= k?  Q = this boundary's thresholds on z / x for the regions
 // x > 0, x < 0 < z, x < 0 and z < 0.  1 / 0, or -1 when the question is not one for this test (a zero, a NaN, no table entry).
 SKYTAB_HD inline int side_q(const double *Q, double x, double z) {

@@ -189,7 +189,7 @@ struct Replica {
   double *d_plane_boxes = nullptr;
   double *d_tri_normals = nullptr;
   void *d_sky = nullptr;
-  double *d_sky_u_tab = nullptr, *d_sky_u_q = nullptr, *d_sky_v_tab = nullptr;
+  double *d_sky_u_tab = nullptr, *d_sky_u_q = nullptr;
   KScene ks{};
   int n_internal = 0, depth = 0;
   bool has_boxed_planes = false;        // some plane sits in a non-root leaf: its visibility can depend on the reference's traversal (literal_hit)
@@ -230,7 +230,7 @@ static void replica_destroy(Replica *s) {
   (void)hipSetDevice(s->device);
   (void)hipFree(s->d_nodes32); (void)hipFree(s->d_nodes64); (void)hipFree(s->d_prims); (void)hipFree(s->d_prim_ids);
   (void)hipFree(s->d_fnodes32); (void)hipFree(s->d_fprims); (void)hipFree(s->d_ref_anc); (void)hipFree(s->d_ref_depth); (void)hipFree(s->d_leaf_anc);
-  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky); (void)hipFree(s->d_sky_u_tab); (void)hipFree(s->d_sky_u_q); (void)hipFree(s->d_sky_v_tab);
+  (void)hipFree(s->d_mats); (void)hipFree(s->d_lights); (void)hipFree(s->d_plane_boxes); (void)hipFree(s->d_tri_normals); (void)hipFree(s->d_sky); (void)hipFree(s->d_sky_u_tab); (void)hipFree(s->d_sky_u_q);
   (void)hipFree(s->ws.counter); (void)hipFree(s->ws.stats); (void)hipFree(s->ws.fscratch); (void)hipFree(s->ws.samples); (void)hipFree(s->ws.tiles);
   (void)hipFree(s->d_color); (void)hipFree(s->d_radiance); (void)hipFree(s->d_primid); (void)hipFree(s->d_rgb8);
   if (s->p_color != s->g_color) { (void)hipFree(s->p_color); (void)hipFree(s->p_radiance); (void)hipFree(s->p_primid); (void)hipFree(s->p_rgb8); }
@@ -607,8 +607,12 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
     UP(dev_upload(&p, (const uint8_t *)hs.sky, hs.sky_bytes));
     s->d_sky = p;
     UP(dev_upload(&s->d_sky_u_tab, hs.sky_u_tab.data(), hs.sky_u_tab.size()));
-    UP(dev_upload(&s->d_sky_u_q, hs.sky_u_q.data(), hs.sky_u_q.size()));
-    UP(dev_upload(&s->d_sky_v_tab, hs.sky_v_tab.data(), hs.sky_v_tab.size()));
+    {                                                  // one table: (w, h), Q_k[3] ..., T_k ...: sky_texel_exact takes one pointer
+      std::vector<double> t{(double)hs.ks.sky_w, (double)hs.ks.sky_h};
+      t.insert(t.end(), hs.sky_u_q.begin(), hs.sky_u_q.end());
+      t.insert(t.end(), hs.sky_v_tab.begin(), hs.sky_v_tab.end());
+      UP(dev_upload(&s->d_sky_u_q, t.data(), t.size()));
+    }
   }
   uint32_t zero = 0;
   UP(dev_upload(&s->ws.counter, &zero, 1));
@@ -621,7 +625,7 @@ static int upload_replica(const HostScene &hs, int device, Replica **out) {
   k.nodes = s->d_nodes32; k.prims = s->d_prims; k.tprims = s->d_prims;
   k.ref_nodes64 = s->d_nodes64; k.ref_anc = s->d_ref_anc; k.ref_depth = s->d_ref_depth; k.leaf_anc = s->d_leaf_anc;
   k.prim_ids = s->d_prim_ids; k.mats = s->d_mats; k.lights = s->d_lights;
-  k.plane_boxes = s->d_plane_boxes; k.shade_recs = s->d_tri_normals; k.sky = s->d_sky; k.sky_u_tab = s->d_sky_u_tab; k.sky_u_q = s->d_sky_u_q; k.sky_v_tab = s->d_sky_v_tab;
+  k.plane_boxes = s->d_plane_boxes; k.shade_recs = s->d_tri_normals; k.sky = s->d_sky; k.sky_u_tab = s->d_sky_u_tab; k.sky_u_q = s->d_sky_u_q ? s->d_sky_u_q + 2 : nullptr; k.sky_v_tab = s->d_sky_u_q ? s->d_sky_u_q + 2 + hs.sky_u_q.size() : nullptr;
   *out = s;
   return RT_OK;
 }

@@ -3,7 +3,7 @@
 are comment-only inline asm statements, `; RTMARK <name>`, placed at the body boundaries in rt_render_kernel.h).
     python tools/isa_counts.py [float,false,true]  > profiles/rNN_isa_counts.txt
 Counts are per WAVE-LEVEL pass through the straight-line text between two markers (static, not weighted by how often a
-section runs; out-of-line functions - pow, literal_hit, tie_candidate_wins, sky_texel_cold - are listed separately)."""
+section runs; out-of-line functions - pow, literal_hit, tie_candidate_wins, sky_texel_exact - are listed separately)."""
 import collections
 import os
 import re
