@@ -22,7 +22,17 @@ def scale(s, v): return (s * v[0], s * v[1], s * v[2])
 def mul(a, b): return (a[0] * b[0], a[1] * b[1], a[2] * b[2])
 def negate_v(v): return (-v[0], -v[1], -v[2])
 def v_length(v): return math.sqrt(dot(v, v))
-def normalize(v): return scale(1 / v_length(v), v)                      # :78-79
+def fdiv(a, b):
+    """IEEE division, as `/` on Double is under GHC: x / 0 is +-inf or NaN where Python raises ZeroDivisionError."""
+    try:
+        return a / b
+    except ZeroDivisionError:
+        if a != a or a == 0:
+            return math.nan
+        return math.copysign(math.inf, a) * math.copysign(1.0, b)
+
+
+def normalize(v): return scale(fdiv(1, v_length(v)), v)                      # :78-79
 def reflect(v, n): return sub(v, scale(2 * dot(v, n), n))              # :98-99
 
 
@@ -68,7 +78,7 @@ def hit_prim(o, ray, iv):
         a = dot(e1, h)
         if abs(a) < 1e-8:
             return None
-        f = 1.0 / a
+        f = fdiv(1.0, a)
         s = sub(org, p0)
         u = f * dot(s, h)
         if u < 0.0 or u > 1.0:
@@ -90,17 +100,17 @@ def hit_prim(o, ray, iv):
         disc = h * h - a * (dot(oc, oc) - r * r)
         if disc < 0:
             return None
-        t1 = (-h - math.sqrt(disc)) / a                                # the near root only
+        t1 = fdiv(-h - math.sqrt(disc), a)                                # the near root only
         if not contains(iv, t1):
             return None
         p = at(ray, t1)
-        nrm, front = set_face_normal(ray, scale(1.0 / r, sub(p, c)))
+        nrm, front = set_face_normal(ray, scale(fdiv(1.0, r), sub(p, c)))
         return {"point": p, "normal": nrm, "t": t1, "front": front, "mat": o[3], "id": o[4]}
     p, n = o[1], o[2]                                                  # Plane.hs:21-32
     denom = dot(d, n)
     if not abs(denom) > 1e-6:
         return None
-    t = dot(sub(p, org), n) / denom
+    t = fdiv(dot(sub(p, org), n), denom)
     if not contains(iv, t):
         return None
     nrm, front = set_face_normal(ray, n)
@@ -118,7 +128,7 @@ def hit_aabb_interval(box, ray, iv):
     def check_axis(o, dd, mn, mx):
         if abs(dd) < 1e-8:
             return None if (o < mn or o > mx) else (-INF, INF)
-        inv = 1.0 / dd
+        inv = fdiv(1.0, dd)
         t0, t1 = (mn - o) * inv, (mx - o) * inv
         return (min(t0, t1), max(t0, t1))
 
@@ -220,7 +230,7 @@ def compute_lighting(rec, lights, world):
             if hit_bvh(world, (hit_point, to_light), (0.001, dist - 0.01)) is not None:
                 return (0.0, 0.0, 0.0)
             power = max(0, dot(hit_normal, to_light))
-            return scale(power * (1 / (dist * dist)), light["intensity"])
+            return scale(power * fdiv(1, dist * dist), light["intensity"])
         to_light = normalize(scale(-1, light["vec"]))
         if hit_bvh(world, (hit_point, to_light), (0.001, 10000)) is not None:
             return (0.0, 0.0, 0.0)
@@ -234,9 +244,27 @@ def compute_lighting(rec, lights, world):
 
 # ---------------------------------------------------------------- Rendering/Trace.hs:19-94
 def schlick(cosine, ref_idx):
-    r0 = (1 - ref_idx) / (1 + ref_idx)
+    r0 = fdiv(1 - ref_idx, 1 + ref_idx)
     r0sq = r0 * r0
-    return r0sq + (1 - r0sq) * ((1 - cosine) ** 5)
+    return r0sq + (1 - r0sq) * hs_pow(1 - cosine, 5.0)
+
+
+def hs_floor_int(x):
+    """floor :: Double -> Int (GHC's floorDoubleInt, a cvttsd2si on x86-64): a NaN or a value out of range gives minBound."""
+    if x != x or abs(x) >= 9.223372036854775807e18:
+        return -(1 << 63)
+    return int(math.floor(x))
+
+
+def hs_pow(x, y):
+    """(**) on Double = libm's pow (GHC.Float powerDouble): NaN for a negative base with a fractional exponent, +-inf on overflow
+    and for 0 ** negative - where Python's ** returns a complex number or raises."""
+    try:
+        return math.pow(x, y)
+    except OverflowError:
+        return math.inf if (x > 0 or float(y).is_integer() and int(y) % 2 == 0) else -math.inf
+    except ValueError:
+        return math.inf if x == 0 else math.nan
 
 
 def hs_atan2(y, x):
@@ -244,11 +272,11 @@ def hs_atan2(y, x):
     RealFloat Double does not define atan2, so libm's atan2 is never called: division, atan and `pi + ...` each round."""
     neg_zero = lambda v: v == 0.0 and math.copysign(1.0, v) < 0
     if x > 0:
-        return math.atan(y / x)
+        return math.atan(fdiv(y, x))
     if x == 0 and y > 0:
         return math.pi / 2
     if x < 0 and y > 0:
-        return math.pi + math.atan(y / x)
+        return math.pi + math.atan(fdiv(y, x))
     if (x <= 0 and y < 0) or (x < 0 and neg_zero(y)) or (neg_zero(x) and neg_zero(y)):
         return -hs_atan2(-y, x)
     if y == 0 and (x < 0 or neg_zero(x)):
@@ -288,7 +316,7 @@ def trace_ray(scene, ray0, max_depth, draw):
         rand_vec = normalize((rx, ry, rz))
         if mat.get("transmission") == 1.0 and mat.get("ior") is not None:
             ior = mat["ior"]
-            eta = 1.0 / ior if rec["front"] else ior
+            eta = fdiv(1.0, ior) if rec["front"] else ior
             cos_theta = hs_min(-dot(unit_dir, n), 1.0)
             sin_theta = math.sqrt(1.0 - cos_theta * cos_theta)
             if eta * sin_theta > 1.0 or rd_ < schlick(cos_theta, eta):
@@ -370,8 +398,8 @@ def render(scene, cam, width, height, spp, antialiasing, max_bounces, exposure, 
             for c in samples:                                          # foldl' add, RenderWorker.hs:111-114
                 acc = add(acc, c)
             avg = scale(1.0 / float(len(samples)), acc)
-            toned = tuple(x * exposure / (x * exposure + 1) for x in avg)          # Trace.hs:96-101
-            gammaed = tuple(x ** gamma for x in toned)                              # Trace.hs:103-105
+            toned = tuple(fdiv(x * exposure, x * exposure + 1) for x in avg)          # Trace.hs:96-101
+            gammaed = tuple(hs_pow(x, gamma) for x in toned)                            # Trace.hs:103-105
             rr.append(avg); cc.append(gammaed); ii.append(first_id)
             # RenderWorker.hs:108-109 truncate (c * 255.999); the 8-bit output convention of include/rtcore.h (rt_output.rgb8): clamped
             # to 0..255, NaN -> 0 (the reference would `show` an out-of-range integer there)
@@ -411,8 +439,8 @@ def scene_from_spec(spec):
             dx, dy, dz = normalize(ray[1])
             u = 0.5 + hs_atan2(dz, dx) / (2 * math.pi)
             v = 0.5 - math.asin(dy) / math.pi
-            i = max(0, min(int(math.floor(u * float(sw))), sw - 1))
-            j = max(0, min(int(math.floor(v * float(sh))), sh - 1))
+            i = max(0, min(hs_floor_int(u * float(sw)), sw - 1))
+            j = max(0, min(hs_floor_int(v * float(sh)), sh - 1))
             p = img[j, i]
             return tuple(float(x) / 255 for x in p) if fmt == "rgb8" else tuple(float(x) for x in p)
     elif bg["tag"] == "SolidColor":

@@ -19,3 +19,8 @@ def test_restatements_agree_on_random_scenes():
 
 def test_restatements_agree_on_extreme_scenes():
     run("0", "30", "--extreme")
+
+
+def test_restatements_agree_on_degenerate_inputs():
+    """zero-direction lights, lights on surfaces, zero-area triangles, a plane of normal 0, ior 0 / 1, NaN camera bases (fuzz_oracle --degenerate)"""
+    run("0", "30", "--degenerate")

@@ -4,7 +4,7 @@ triangles, spheres (a few with negative or zero radius), planes of random point 
 glass / metal / emissive materials, point and directional lights, gradient / solid / LDR / HDR sky, thin lens, random
 leafThreshold / bvhMaxDepth / maxBounces, Russian roulette on some seeds; all three box_precision modes.
 Prints one line per seed; exit status 1 if any pixel's id differs or any radiance differs by more than 1e-12 (relative to
-max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme] [--axis] [--nan]"""
+max(1, |radiance|)).      python tools/fuzz_oracle.py <first seed> <last seed + 1>   |   --seeds 180,712   [--big] [--extreme] [--axis] [--nan] [--degenerate]"""
 import os
 import sys
 
@@ -175,9 +175,59 @@ def scene_nan(seed):
     return spec, rr
 
 
+def scene_degenerate(seed):
+    """The standard family with inputs a config file can hold and a careful user would not write: a directional light of
+    direction 0 (normalize gives NaN), lights ON a surface point, at a sphere's centre or at the camera, zero / negative / huge
+    intensities, triangles of zero area and of one point, a plane of normal 0, glass of ior 1 and ior 0, shininess 0, a lens with
+    focus distance 0, a 1e-4 degree field of view, exposure 0, and (one seed in eight) vUp along the view direction: a NaN camera
+    basis, every ray NaN.  Nothing here is physically meaningful; the reference still computes SOMETHING for each, by the
+    comparison and min / max rules of its operators, and the kernel must compute the same."""
+    spec, rr = scene(seed)
+    rng = np.random.default_rng(55_000_000 + seed)
+    m = spec.obj_meshes[0]
+    tri0 = (m.verts[m.faces[0]] + np.asarray(m.position)) if len(m.faces) else np.zeros((3, 3))
+    picks = set(int(x) for x in rng.choice(14, size=int(rng.integers(1, 5)), replace=False))
+    if 0 in picks:
+        spec.lights.append({"tag": "DirectionalLight", "direction": [0.0, 0.0, 0.0], "intensity": [0.5, 0.4, 0.3]})
+    if 1 in picks:                                               # a light exactly at a triangle vertex / inside the triangle's plane
+        spec.lights.append({"tag": "PointLight", "position": [float(x) for x in tri0[0]], "intensity": list(rng.uniform(5, 60, 3))})
+        spec.lights.append({"tag": "PointLight", "position": [float(x) for x in tri0.mean(0)], "intensity": list(rng.uniform(5, 60, 3))})
+    if 2 in picks:
+        for c in spec.config_objects:
+            if c[0] == "sphere":
+                spec.lights.append({"tag": "PointLight", "position": list(c[1]), "intensity": [20.0, 20.0, 20.0]}); break
+    if 3 in picks:
+        spec.lights.append({"tag": "PointLight", "position": list(spec.camera["lookFrom"]), "intensity": [30.0, 0.0, -5.0]})
+    if 4 in picks:
+        spec.lights.append({"tag": "PointLight", "position": list(rng.uniform(-5, 5, 3)), "intensity": [1e300, 1e-300, 0.0]})
+    if 5 in picks:                                               # zero-area triangles
+        v = rng.uniform(-3, 3, size=(2, 3))
+        spec.config_objects.append(("triangle", list(v[0]), list(v[0]), list(v[1]), "matte"))
+        spec.config_objects.append(("triangle", list(v[1]), list(v[1]), list(v[1]), "metal"))
+        spec.config_objects.append(("triangle", list(v[0]), list((v[0] + v[1]) / 2), list(v[1]), "glass"))
+    if 6 in picks:
+        spec.config_objects.append(("plane", list(rng.uniform(-1, 1, 3)), [0.0, 0.0, 0.0], "matte"))
+    if 7 in picks:
+        spec.materials[2] = ("glass", {"diffuseColor": [1.0, 1.0, 1.0], "ior": float(rng.choice([1.0, 0.0, -1.5, 1e-9])), "transmission": float(rng.choice([1.0, 0.5, 0.0]))})
+    if 8 in picks:
+        spec.materials[1] = ("metal", {"diffuseColor": [0.9, -0.2, 1.7], "shininess": float(rng.choice([0.0, -3.0, 1e9]))})
+    if 9 in picks:
+        spec.camera["aperture"] = 0.4; spec.camera["focusDist"] = 0.0
+    if 10 in picks:
+        spec.camera["vfov"] = float(rng.choice([1e-4, 179.999, 180.0]))
+    if 11 in picks:
+        spec.exposure = 0.0
+    if 12 in picks:
+        spec.gamma = float(rng.choice([1e-3, 1e3]))
+    if 13 in picks and seed % 2 == 0:                            # vUp along the view direction: cross product 0, normalize NaN
+        lf, la = np.asarray(spec.camera["lookFrom"]), np.asarray(spec.camera["lookAt"])
+        spec.camera["vUp"] = [float(x) for x in (la - lf)]
+    return spec, rr
+
+
 def main():
-    big, extreme, axis, nan = "--big" in sys.argv, "--extreme" in sys.argv, "--axis" in sys.argv, "--nan" in sys.argv
-    for f in ("--big", "--extreme", "--axis", "--nan"):
+    big, extreme, axis, nan, degen = "--big" in sys.argv, "--extreme" in sys.argv, "--axis" in sys.argv, "--nan" in sys.argv, "--degenerate" in sys.argv
+    for f in ("--big", "--extreme", "--axis", "--nan", "--degenerate"):
         if f in sys.argv:
             sys.argv.remove(f)
     if len(sys.argv) > 2 and sys.argv[1] == "--seeds":
@@ -186,7 +236,7 @@ def main():
         seeds = range(*((int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)))
     bad = 0
     for seed in seeds:
-        spec, rr = scene_axis(seed) if axis else (scene_nan(seed) if nan else scene(seed, big, extreme))
+        spec, rr = scene_axis(seed) if axis else (scene_nan(seed) if nan else (scene_degenerate(seed) if degen else scene(seed, big, extreme)))
         o = O.OracleScene(spec)
         ref = o.render(rr_start_bounce=rr, n_threads=min(16, os.cpu_count() or 8))
         o.close()

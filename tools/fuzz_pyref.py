@@ -3,7 +3,7 @@
 random scenes of tools/fuzz_oracle.py at postage-stamp size (pyref is pure Python): spheres of radius <= 0 (inside-out boxes),
 planes anywhere, duplicated triangles, depth-limited and one-object leaves, all materials, both light kinds, sky textures, thin lens.
 Ids equal, radiance bit-identical, 8-bit frame equal - the bar of tests/test_oracle_pyref.py.
-    python tools/fuzz_pyref.py <first seed> <last seed + 1> [--extreme]"""
+    python tools/fuzz_pyref.py <first seed> <last seed + 1> [--extreme | --degenerate]"""
 import os
 import sys
 
@@ -17,13 +17,14 @@ from oracle import pyref                            # noqa: E402
 
 
 def main():
-    extreme = "--extreme" in sys.argv
-    if extreme:
-        sys.argv.remove("--extreme")
+    extreme, degen = "--extreme" in sys.argv, "--degenerate" in sys.argv
+    for f in ("--extreme", "--degenerate"):
+        if f in sys.argv:
+            sys.argv.remove(f)
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
     bad = 0
     for seed in range(lo, hi):
-        spec, _ = FZ.scene(seed, False, extreme)
+        spec, _ = FZ.scene_degenerate(seed) if degen else FZ.scene(seed, False, extreme)
         m = spec.obj_meshes[0]
         if len(m.faces) > 300:                      # keep pure Python in seconds: the first 300 triangles
             m.faces = m.faces[:300]
