@@ -14,6 +14,7 @@
 #include "rt_device.h"
 #include "../../include/rtcore.h"
 #include "rt_sky_tables.h"
+#include "rt_pow5.h"
 
 struct KScene {
   const void *nodes;           // DNode<BT>[] of the tree the kernel traverses

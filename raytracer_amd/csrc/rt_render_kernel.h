@@ -781,8 +781,7 @@ __global__ __launch_bounds__(RT_BLOCK_THREADS, RT_MIN_WAVES) void k_render_tiles
             const double sinTheta = sqrt(1.0 - cosTheta * cosTheta);
             const double r0 = (1 - eta) / (1 + eta);                             // schlick, :85-89
             const double r0sq = r0 * r0;
-            const double omc = 1 - cosTheta;                                     // (1-cos)**5 by multiplication: <= 1 ulp from pow()
-            const double reflectProb = r0sq + (1 - r0sq) * (omc * omc * omc * omc * omc);
+            const double reflectProb = r0sq + (1 - r0sq) * pow5_cr(1 - cosTheta);   // (1-cos)**5 correctly rounded = libm's pow but for 1 x in 1,000 (rt_pow5.h)
             if (eta * sinTheta > 1.0 || randD < reflectProb) rd = reflect3(udir, nrm);
             else rd = refract3(udir, nrm, eta);
           } else if (M.flags & DMAT_METAL) {                                     // :60-64
