@@ -33,12 +33,15 @@ def sweep_camera(c, t, s, step):
 
 
 def directions(cam):
-    """The primary directions of a frame as Camera.hs:54-60 computes them (no jitter, no lens)."""
+    """The directions the sky lookup sees for a frame's primary rays (Camera.hs:54-60 without jitter or lens, then SkySphere.hs:34)."""
     px, py = np.meshgrid(np.arange(W), np.arange(H))
     ru, rv = (px + 0.5) / W, ((H - 1 - py) + 0.5) / H
     ll, hor, ver = (np.array(list(v)) for v in (cam.lower_left, cam.horizontal, cam.vertical))
     d = (ll[None, None, :] + ru[..., None] * hor) + rv[..., None] * ver
-    return d / np.sqrt((d * d).sum(-1))[..., None]
+    for _ in range(2):                                                  # Camera.hs:60 normalises the ray, SkySphere.hs:34 normalises it again
+        dot = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]
+        d = (1.0 / np.sqrt(dot))[..., None] * d                         # Vec3.hs:78-79: scale (1 / vLength v) v
+    return d
 
 
 def probe(sw, sh, steps=(1e-18, 1e-17, 1e-16, 1e-15, 1e-14, 1e-13), verbose=True):
