@@ -26,13 +26,20 @@ bool ends_with(const std::string &s, const char *suf) {
 }
 // RGBE -> float.  PARITY UNPINNED: the reference decodes through JuicyPixels' readImage, whose source is not part of the
 // reference checkout and cannot be imported here, and the reference holds no decoded fixture.  This follows JuicyPixels'
-// Codec.Picture.HDR.toFloat as recalled - (mantissa + 0.5) * 2^(e - 136) for every exponent, with no special case for
-// e = 0 (which yields a denormal ~1e-41 rather than 0: invisible next to the 1e-12 of the parity tests) - and the only
-// thing tests/test_config_loader.py pins is this formula itself.  If JuicyPixels truncates instead (mantissa * 2^(e - 136))
-// every texel here is half a mantissa step too bright: 0.2-0.4 % on the dominant channel.
+// Codec.Picture.HDR.toFloat as recalled:
+//     f = encodeFloat 1 (e - (128 + 8));  rf = (fromIntegral r + 0.0) * f   (likewise g, b)
+// - mantissa * 2^(e - 136) for every exponent (e = 0 gives 0 only because the mantissas of a black texel are 0), WITHOUT the
+// half-step offset of Radiance's own (m + 0.5) reader.  Rounds 1-2 of this repository recalled the line with + 0.5; the `+ 0.0`
+// is the more specific memory (it reads like the trace of exactly that edit), so it is the default now, and RTH_RGBE_HALF=1 in
+// the environment selects the other reading: 0.2-0.4 % brighter on a texel's dominant channel, more on the small mantissas.
+// Whichever JuicyPixels does, the render core is handed floats and is exact for them; only this loader is in question.
+float rgbe_offset() {
+  static const float off = [] { const char *e = std::getenv("RTH_RGBE_HALF"); return e && e[0] == '1' ? 0.5f : 0.0f; }();
+  return off;
+}
 void rgbe_to_float(const unsigned char *p, float *out) {
-  float f = std::ldexp(1.0f, (int)p[3] - (128 + 8));
-  out[0] = (p[0] + 0.5f) * f; out[1] = (p[1] + 0.5f) * f; out[2] = (p[2] + 0.5f) * f;
+  const float f = std::ldexp(1.0f, (int)p[3] - (128 + 8)), off = rgbe_offset();
+  out[0] = (p[0] + off) * f; out[1] = (p[1] + off) * f; out[2] = (p[2] + off) * f;
 }
 int load_hdr(FILE *f, int32_t *w, int32_t *h, void **pixels) {
   char line[512];

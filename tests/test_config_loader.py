@@ -140,7 +140,7 @@ def test_ppm_body_is_byte_exact(tmp_path):
 
 
 def test_sky_loader(tmp_path):
-    # flat (non-RLE) Radiance file, 2x1: RGBE (128,64,32,129) -> (m+0.5)*2^(e-136)
+    # flat (non-RLE) Radiance file, 2x1: RGBE (128,64,32,129) -> m * 2^(e-136)  (JuicyPixels' toFloat as recalled: rthost_sky.cpp)
     hdr = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 2\n" + bytes([128, 64, 32, 129, 0, 0, 0, 0])
     p = tmp_path / "s.hdr"
     p.write_bytes(hdr)
@@ -149,7 +149,7 @@ def test_sky_loader(tmp_path):
     a = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), shape=(6,)).copy()
     F.host().rth_sky_free(px)
     assert (fmt.value, w.value, h.value) == (F.RT_SKY_RGBF, 2, 1)
-    assert np.allclose(a, [128.5 / 128, 64.5 / 128, 32.5 / 128, 0, 0, 0])
+    assert a.tolist() == [128 / 128, 64 / 128, 32 / 128, 0, 0, 0]
     q = tmp_path / "s.ppm"
     q.write_bytes(b"P6\n2 1\n255\n" + bytes([1, 2, 3, 4, 5, 6]))
     F.check(F.host().rth_sky_load(str(q).encode(), C.byref(fmt), C.byref(w), C.byref(h), C.byref(px)), "host")
