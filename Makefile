@@ -26,10 +26,14 @@ oracle: oracle/_build/liboracle.so
 # ~1e-16, no primitive-id mismatches); the FP32 box tests use explicit fmaf and are not affected.
 # RT_BUILD_ID: digest of the kernel sources + compile-time knobs, returned by rt_build_id(); counter records under profiles/
 # carry it so that bench.py can tell when they were taken on another kernel
-raytracer_amd/lib/librtcore.so: $(CORE_SRC) $(CORE_HDR)
+# CORE_OPT: -O2, measured against -O3 / -Os / -O1 / -fno-slp-vectorize / -fno-unroll-loops on one box (tools/ab.sh): C4 40.86 ms at -O2,
+# 41.17 at -O3, 40.91 at -Os, 41.72 at -O1; C5 508.5 against 514.7, C2 14.11 against 14.18, C3 15.58 against 15.68.  No fast-math at
+# any level: the results are the same bits.
+CORE_OPT ?= -O2
+raytracer_amd/lib/librtcore.so: $(CORE_SRC) $(CORE_HDR) Makefile
 	@mkdir -p raytracer_amd/lib
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(KERNEL_DEFS) \
-	    -DRT_BUILD_ID=\"$$( (cat $(CORE_SRC) $(sort $(CORE_HDR)); echo "$(RT_MIN_WAVES) $(KERNEL_DEFS)") | sha256sum | cut -c1-16)\" $(CORE_SRC) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) $(CORE_OPT) -std=c++17 -fPIC -shared -ffp-contract=off -DRT_MIN_WAVES=$(RT_MIN_WAVES) $(KERNEL_DEFS) \
+	    -DRT_BUILD_ID=\"$$( (cat $(CORE_SRC) $(sort $(CORE_HDR)); echo "$(RT_MIN_WAVES) $(KERNEL_DEFS) $(CORE_OPT)") | sha256sum | cut -c1-16)\" $(CORE_SRC) -o $@
 
 # -ffp-contract=off: the BVH builder's sort keys must round exactly like the reference's doubles
 raytracer_amd/lib/librthost.so: $(HOST_SRC) $(HOST_HDR)

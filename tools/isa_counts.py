@@ -20,7 +20,7 @@ sym = f"_Z14k_render_tilesI{tmpl}Ev6KScene6KFrame"
 
 with tempfile.TemporaryDirectory() as td:
     out = os.path.join(td, "k.s")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DRT_MIN_WAVES=4", "-DRT_ASM_MARKERS",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-DRT_MIN_WAVES=4", "-DRT_ASM_MARKERS",
                            "--cuda-device-only", "-S", os.path.join(ROOT, "raytracer_amd/csrc/rtcore.hip"), "-o", out])
     text = open(out).read().splitlines()
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Register / spill metadata of the timed kernel instantiations (compile only; no GPU needed):  tools/spills.sh [extra hipcc flags]
 out=$(mktemp /tmp/rtk.XXXXXX.s)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DRT_MIN_WAVES=4 "$@" --cuda-device-only -S raytracer_amd/csrc/rtcore.hip -o $out || exit 1
+hipcc --offload-arch=gfx950 -O2 -std=c++17 -ffp-contract=off -DRT_MIN_WAVES=4 "$@" --cuda-device-only -S raytracer_amd/csrc/rtcore.hip -o $out || exit 1
 python3 - "$out" <<'PY'
 import re, sys
 t = open(sys.argv[1]).read()
